@@ -1,0 +1,874 @@
+// fedagg.hip -- gfx950 kernels and C ABI for the FedAvg-family aggregation hot path.
+//
+// All kernels are HBM-bound streaming kernels: every thread owns whole 16-byte vectors of the
+// flat parameter axis, walks the K client buffers in client order for its vectors and keeps
+// the running step in registers, so each client byte is read once and g / m / v are read and
+// written once per launch.  Client pointers and weights travel in the kernel-argument block
+// and are fetched by scalar loads (wave-uniform), which leaves one `global_load_dwordx4
+// v, v_off, s[base]` per client per vector in the inner loop.
+//
+// Built with -ffp-contract=off: the formulas are sequences of separately rounded fp32 ops.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "../../include/appfl_amd.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 1 << 16;   // grid cap; larger inputs are walked grid-stride
+
+struct Hyper {
+    float lr, b1, omb1, b2, omb2, tau;
+};
+
+struct ReduceArgs {
+    const float* x[FA_KCHUNK];
+    float w[FA_KCHUNK];
+    float* g;
+    float* m;
+    float* v;
+    const float* step_in;  // partial step of earlier client chunks (NULL: start from 0)
+    float* step_out;       // where the partial / final step goes (NULL: nowhere)
+    const float* g_ro;     // read-only g for step-only mode
+    unsigned n;            // elements of width VEC
+    int K;
+    int last;   // 1: run the optimizer epilogue and the apply
+    int apply;  // 1: write g (0 = step-only mode)
+    Hyper h;
+};
+
+template <int VEC>
+struct Pack {
+    float e[VEC];
+};
+
+// Client bytes are read exactly once: `nt` loads keep them from displacing g / m / v in L2.
+template <int VEC, bool NT = true>
+__device__ __forceinline__ Pack<VEC> load_stream(const float* p, unsigned i) {
+    Pack<VEC> r;
+    if constexpr (VEC == 4) {
+        const f4* q = reinterpret_cast<const f4*>(p) + i;
+        f4 t = NT ? __builtin_nontemporal_load(q) : *q;
+        r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
+    } else {
+        r.e[0] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ Pack<VEC> load_state(const float* p, unsigned i);
+template <>
+__device__ __forceinline__ Pack<4> load_state<4>(const float* p, unsigned i) {
+    f4 t = reinterpret_cast<const f4*>(p)[i];
+    Pack<4> r;
+    r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
+    return r;
+}
+template <>
+__device__ __forceinline__ Pack<1> load_state<1>(const float* p, unsigned i) {
+    Pack<1> r;
+    r.e[0] = p[i];
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_state(float* p, unsigned i, const Pack<VEC>& r);
+template <>
+__device__ __forceinline__ void store_state<4>(float* p, unsigned i, const Pack<4>& r) {
+    f4 t;
+    t.x = r.e[0]; t.y = r.e[1]; t.z = r.e[2]; t.w = r.e[3];
+    reinterpret_cast<f4*>(p)[i] = t;
+}
+template <>
+__device__ __forceinline__ void store_state<1>(float* p, unsigned i, const Pack<1>& r) {
+    p[i] = r.e[0];
+}
+
+__device__ __forceinline__ float sign_f32(float d) {
+    // torch.sign: (0 < d) - (d < 0); NaN and both zeros give 0.
+    return static_cast<float>(static_cast<int>(0.0f < d) - static_cast<int>(d < 0.0f));
+}
+
+// Turns the averaged pseudo-gradient into the server-optimizer step; updates m / v in place.
+template <int OPT>
+__device__ __forceinline__ float optimizer_step(float step, float& m, float& v, const Hyper& h) {
+    if (OPT == FA_OPT_NONE) return step;
+    if (OPT == FA_OPT_AVGM) {
+        float mt = v * h.b1;
+        v = mt + step;
+        return v;
+    }
+    float mt = m * h.b1;
+    float st = step * h.omb1;
+    m = mt + st;
+    float s2 = step * step;
+    if (OPT == FA_OPT_ADAM) {
+        float vt = v * h.b2;
+        float sq = s2 * h.omb2;
+        v = vt + sq;
+    } else if (OPT == FA_OPT_YOGI) {
+        float sg = sign_f32(v - s2);
+        float yu = s2 * sg;
+        float ys = yu * h.omb2;
+        v = v - ys;
+    } else {  // FA_OPT_ADAGRAD
+        v = v + s2;
+    }
+    float num = h.lr * m;
+    // sqrtf and / lower to the correctly rounded sequences (hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt); the __fsqrt_rn intrinsic is the 1-ulp v_sqrt_f32.
+    float den = sqrtf(v) + h.tau;
+    return num / den;
+}
+
+// One tile = kThreads * VPT vectors; a thread owns vectors tile_base + p * kThreads + tid.
+// In the one partial tile (GUARD) out-of-range threads redo the last vector's loads and skip
+// the stores, so the instruction stream is the unguarded one.
+template <int OPT, int VEC, int VPT, int U, bool NT, bool GUARD>
+__device__ __forceinline__ void reduce_tile(const ReduceArgs& a, unsigned base) {
+    unsigned idx[VPT];
+    bool ok[VPT];
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+        unsigned i = base + p * kThreads + threadIdx.x;
+        ok[p] = !GUARD || i < a.n;
+        idx[p] = ok[p] ? i : a.n - 1;
+    }
+    const float* gsrc = a.apply ? a.g : a.g_ro;
+    Pack<VEC> g[VPT], s[VPT];
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+        g[p] = load_state<VEC>(gsrc, idx[p]);
+        if (a.step_in) {
+            s[p] = load_state<VEC>(a.step_in, idx[p]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s[p].e[j] = 0.0f;
+        }
+    }
+    int k = 0;
+    for (; k + U <= a.K; k += U) {
+        Pack<VEC> xv[U][VPT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) xv[u][p] = load_stream<VEC, NT>(a.x[k + u], idx[p]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float wk = a.w[k + u];
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float d = xv[u][p].e[j] - g[p].e[j];
+                    float wd = d * wk;
+                    s[p].e[j] = s[p].e[j] + wd;
+                }
+            }
+        }
+    }
+    for (; k < a.K; ++k) {
+        const float wk = a.w[k];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            Pack<VEC> xv = load_stream<VEC, NT>(a.x[k], idx[p]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float d = xv.e[j] - g[p].e[j];
+                float wd = d * wk;
+                s[p].e[j] = s[p].e[j] + wd;
+            }
+        }
+    }
+    if (!a.last) {
+#pragma unroll
+        for (int p = 0; p < VPT; ++p)
+            if (ok[p]) store_state<VEC>(a.step_out, idx[p], s[p]);
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+        if (OPT != FA_OPT_NONE) {
+            Pack<VEC> m, v;
+            v = load_state<VEC>(a.v, idx[p]);
+            if (OPT != FA_OPT_AVGM) m = load_state<VEC>(a.m, idx[p]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float mj = (OPT != FA_OPT_AVGM) ? m.e[j] : 0.0f;
+                s[p].e[j] = optimizer_step<OPT>(s[p].e[j], mj, v.e[j], a.h);
+                if (OPT != FA_OPT_AVGM) m.e[j] = mj;
+            }
+            if (ok[p]) {
+                store_state<VEC>(a.v, idx[p], v);
+                if (OPT != FA_OPT_AVGM) store_state<VEC>(a.m, idx[p], m);
+            }
+        }
+        if (ok[p]) {
+            if (a.step_out) store_state<VEC>(a.step_out, idx[p], s[p]);
+            if (a.apply) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) g[p].e[j] = g[p].e[j] + s[p].e[j];
+                store_state<VEC>(a.g, idx[p], g[p]);
+            }
+        }
+    }
+}
+
+template <int OPT, int VEC, int VPT, int U, bool NT>
+__global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
+    constexpr unsigned kTile = kThreads * VPT;
+    const unsigned full = a.n / kTile;  // tiles that need no bounds check
+    const unsigned tiles = (a.n + kTile - 1) / kTile;
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+        if (t < full)
+            reduce_tile<OPT, VEC, VPT, U, NT, false>(a, t * kTile);
+        else
+            reduce_tile<OPT, VEC, VPT, U, NT, true>(a, t * kTile);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plain mean over clients (entries that bypass the weighted step).
+
+template <typename T>
+struct MeanArgs {
+    const T* x[FA_KCHUNK];
+    T* g;
+    const T* sum_in;  // partial sums of earlier chunks (NULL: 0) -- lives in g between chunks
+    unsigned n;
+    int K;       // clients in this launch
+    int last;    // 1: divide
+    float Kall;  // total client count as fp32
+};
+
+__device__ __forceinline__ float mean_finish(float s, float kf) { return s / kf; }
+__device__ __forceinline__ int64_t mean_finish(int64_t s, float kf) {
+    return static_cast<int64_t>(static_cast<float>(s) / kf);
+}
+__device__ __forceinline__ int32_t mean_finish(int32_t s, float kf) {
+    return static_cast<int32_t>(static_cast<float>(s) / kf);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mean_kernel(const MeanArgs<T> a) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < a.n; i += gridDim.x * kThreads) {
+        T s = a.sum_in ? a.sum_in[i] : static_cast<T>(0);
+        for (int k = 0; k < a.K; ++k) s = s + __builtin_nontemporal_load(a.x[k] + i);
+        a.g[i] = a.last ? mean_finish(s, a.Kall) : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Elementwise kernels: apply, FedAsync mix, FedBuff accumulate / flush, fills.
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void apply_kernel(float* g, const float* step, unsigned n) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        Pack<VEC> gv = load_state<VEC>(g, i), sv = load_stream<VEC>(step, i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) gv.e[j] = gv.e[j] + sv.e[j];
+        store_state<VEC>(g, i, gv);
+    }
+}
+
+// MODE 0: model-based, 1: gradient-based "0 - a*x", 2: gradient-based "a * (-x)".
+template <int MODE>
+__device__ __forceinline__ float async_step(float x, float g, float alpha) {
+    if (MODE == 0) {
+        float d = x - g;
+        return alpha * d;
+    }
+    if (MODE == 1) {
+        float ax = alpha * x;
+        return 0.0f - ax;
+    }
+    float nx = -x;
+    return alpha * nx;
+}
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(kThreads) void async_mix_kernel(const float* x, float alpha, float* g,
+                                                           float* step_out, unsigned n) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        Pack<VEC> xv = load_stream<VEC>(x, i), gv = load_state<VEC>(g, i), sv;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            sv.e[j] = async_step<MODE>(xv.e[j], gv.e[j], alpha);
+            gv.e[j] = gv.e[j] + sv.e[j];
+        }
+        if (step_out) store_state<VEC>(step_out, i, sv);
+        store_state<VEC>(g, i, gv);
+    }
+}
+
+// FLUSH: also g = g + step after the accumulate.
+template <int VEC, int MODE, bool FLUSH>
+__global__ __launch_bounds__(kThreads) void buff_accum_kernel(const float* x, float alpha, float* g,
+                                                            float* step, int first, unsigned n) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        Pack<VEC> xv = load_stream<VEC>(x, i), gv = load_state<VEC>(g, i), sv;
+        if (first) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sv.e[j] = 0.0f;
+        } else {
+            sv = load_state<VEC>(step, i);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = async_step<MODE>(xv.e[j], gv.e[j], alpha);
+            sv.e[j] = sv.e[j] + t;
+            if (FLUSH) gv.e[j] = gv.e[j] + sv.e[j];
+        }
+        store_state<VEC>(step, i, sv);
+        if (FLUSH) store_state<VEC>(g, i, gv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void accum_raw_kernel(const T* x, T* step, int first,
+                                                           unsigned n) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        T s = first ? static_cast<T>(0) : step[i];
+        step[i] = s + x[i];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void flush_mean_kernel(T* g, const T* step, float kf,
+                                                            unsigned n) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        g[i] = mean_finish(step[i], kf);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void fill_kernel(float* p, float value, unsigned n) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        Pack<VEC> r;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) r.e[j] = value;
+        store_state<VEC>(p, i, r);
+    }
+}
+
+__device__ __forceinline__ float synth_noise(uint64_t seed, uint64_t i) {
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + i;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    int s = static_cast<int>(z & 0xFFFF) + static_cast<int>((z >> 16) & 0xFFFF) +
+            static_cast<int>((z >> 32) & 0xFFFF) + static_cast<int>((z >> 48) & 0xFFFF);
+    return static_cast<float>(s - 131070) * 2.6428998e-05f;
+}
+
+__global__ __launch_bounds__(kThreads) void synth_kernel(float* p, const float* base, unsigned n,
+                                                       uint64_t seed, uint64_t first, float scale) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        float t = scale * synth_noise(seed, first + i);
+        p[i] = base ? base[i] + t : t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side.
+
+inline hipStream_t as_stream(fa_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int hip_code(hipError_t e) { return e == hipSuccess ? FA_OK : FA_ERR_HIP - static_cast<int>(e); }
+
+inline int launch_status() { return hip_code(hipGetLastError()); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+inline unsigned grid_for(size_t work_items) {
+    size_t blocks = (work_items + kThreads - 1) / kThreads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > static_cast<size_t>(kMaxBlocks)) blocks = kMaxBlocks;
+    return static_cast<unsigned>(blocks);
+}
+
+// Largest element count one launch indexes with 32-bit vector indices (a multiple of 4).
+constexpr size_t kSegment = size_t(1) << 30;
+
+// Launch shape of the 128-bit reduce kernel.  The defaults are the measured best on MI355X;
+// fa_tune() swaps them at run time so a benchmark can compare shapes inside one process.
+struct Shape {
+    int vpt;         // 16-byte vectors per thread per tile: 1, 2 or 4
+    int unroll;      // clients loaded ahead of the arithmetic: 4, 8 or 16
+    int nt;          // non-temporal client loads
+    int max_blocks;  // grid cap; tiles beyond it are walked grid-stride
+};
+Shape g_shape = {4, 8, 1, kMaxBlocks};
+
+template <int OPT, int VEC, int VPT, int U, bool NT>
+int launch_reduce_s(const ReduceArgs& a, hipStream_t st) {
+    size_t tiles = (static_cast<size_t>(a.n) + kThreads * VPT - 1) / (kThreads * VPT);
+    size_t cap = static_cast<size_t>(g_shape.max_blocks > 0 ? g_shape.max_blocks : kMaxBlocks);
+    unsigned grid = static_cast<unsigned>(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+    hipLaunchKernelGGL((reduce_kernel<OPT, VEC, VPT, U, NT>), dim3(grid), dim3(kThreads), 0, st, a);
+    return launch_status();
+}
+
+template <int OPT, int VPT, int U>
+int launch_reduce_nt(const ReduceArgs& a, hipStream_t st) {
+    return g_shape.nt ? launch_reduce_s<OPT, 4, VPT, U, true>(a, st)
+                      : launch_reduce_s<OPT, 4, VPT, U, false>(a, st);
+}
+
+template <int OPT, int VPT>
+int launch_reduce_u(const ReduceArgs& a, hipStream_t st) {
+    switch (g_shape.unroll) {
+        case 4: return launch_reduce_nt<OPT, VPT, 4>(a, st);
+        case 16: return launch_reduce_nt<OPT, VPT, 16>(a, st);
+        default: return launch_reduce_nt<OPT, VPT, 8>(a, st);
+    }
+}
+
+template <int OPT, int VEC>
+int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
+    if (VEC == 1) return launch_reduce_s<OPT, 1, 1, 8, true>(a, st);
+    switch (g_shape.vpt) {
+        case 1: return launch_reduce_u<OPT, 1>(a, st);
+        case 4: return launch_reduce_u<OPT, 4>(a, st);
+        default: return launch_reduce_u<OPT, 2>(a, st);
+    }
+}
+
+template <int VEC>
+int launch_reduce(int opt, const ReduceArgs& a, hipStream_t st) {
+    switch (opt) {
+        case FA_OPT_NONE: return launch_reduce_t<FA_OPT_NONE, VEC>(a, st);
+        case FA_OPT_AVGM: return launch_reduce_t<FA_OPT_AVGM, VEC>(a, st);
+        case FA_OPT_ADAM: return launch_reduce_t<FA_OPT_ADAM, VEC>(a, st);
+        case FA_OPT_YOGI: return launch_reduce_t<FA_OPT_YOGI, VEC>(a, st);
+        case FA_OPT_ADAGRAD: return launch_reduce_t<FA_OPT_ADAGRAD, VEC>(a, st);
+    }
+    return FA_ERR_INVALID;
+}
+
+struct ReduceCall {
+    const float* const* x;
+    const double* w;
+    int K;
+    float* g;          // written when apply
+    const float* g_ro; // read when !apply
+    float* m;
+    float* v;
+    size_t n;
+    int opt;
+    Hyper h;
+    float* step_out;
+    float* step_ws;
+    int apply;
+};
+
+// Runs [off, off+len) of the flat axis: client chunks of FA_KCHUNK carry the partial step
+// through `carry` (step_out when given, else step_ws).
+int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStream_t st) {
+    const int chunks = (c.K + FA_KCHUNK - 1) / FA_KCHUNK;
+    float* carry = c.step_out ? c.step_out : c.step_ws;
+    for (int ch = 0; ch < chunks; ++ch) {
+        ReduceArgs a;
+        memset(&a, 0, sizeof(a));
+        const int k0 = ch * FA_KCHUNK;
+        a.K = (c.K - k0 < FA_KCHUNK) ? c.K - k0 : FA_KCHUNK;
+        for (int k = 0; k < a.K; ++k) {
+            a.x[k] = c.x[k0 + k] + off;
+            a.w[k] = static_cast<float>(c.w[k0 + k]);
+        }
+        a.g = c.g ? c.g + off : nullptr;
+        a.g_ro = c.g_ro ? c.g_ro + off : nullptr;
+        a.m = c.m ? c.m + off : nullptr;
+        a.v = c.v ? c.v + off : nullptr;
+        a.last = (ch == chunks - 1);
+        a.apply = c.apply;
+        a.step_in = (ch == 0) ? nullptr : carry + off;
+        a.step_out = a.last ? (c.step_out ? c.step_out + off : nullptr) : carry + off;
+        a.h = c.h;
+        a.n = static_cast<unsigned>(vec ? len / 4 : len);
+        int rc = vec ? launch_reduce<4>(c.opt, a, st) : launch_reduce<1>(c.opt, a, st);
+        if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
+}
+
+int reduce_dispatch(const ReduceCall& c, hipStream_t st) {
+    if (!c.x || !c.w || c.K <= 0) return FA_ERR_INVALID;
+    if (c.apply ? !c.g : (!c.g_ro || !c.step_out)) return FA_ERR_INVALID;
+    if (c.opt < FA_OPT_NONE || c.opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
+    if (c.opt != FA_OPT_NONE && !c.v) return FA_ERR_INVALID;
+    if (c.opt >= FA_OPT_ADAM && !c.m) return FA_ERR_INVALID;
+    if (c.K > FA_KCHUNK && !c.step_out && !c.step_ws) return FA_ERR_WORKSPACE;
+    if (c.n == 0) return FA_OK;
+    const void* gp = c.apply ? static_cast<const void*>(c.g) : static_cast<const void*>(c.g_ro);
+    bool a4 = aligned_to(gp, 4), a16 = aligned16(gp);
+    const void* others[] = {c.m, c.v, c.step_out, c.step_ws};
+    for (const void* p : others)
+        if (p) { a4 = a4 && aligned_to(p, 4); a16 = a16 && aligned16(p); }
+    for (int k = 0; k < c.K; ++k) {
+        if (!c.x[k]) return FA_ERR_INVALID;
+        a4 = a4 && aligned_to(c.x[k], 4);
+        a16 = a16 && aligned16(c.x[k]);
+    }
+    if (!a4) return FA_ERR_ALIGN;
+    for (size_t off = 0; off < c.n; off += kSegment) {
+        size_t len = (c.n - off < kSegment) ? c.n - off : kSegment;
+        size_t body = a16 ? (len & ~size_t(3)) : 0;
+        if (body) {
+            int rc = reduce_range(c, off, body, true, st);
+            if (rc != FA_OK) return rc;
+        }
+        if (len > body) {
+            int rc = reduce_range(c, off + body, len - body, false, st);
+            if (rc != FA_OK) return rc;
+        }
+    }
+    return FA_OK;
+}
+
+Hyper make_hyper(double lr, double beta1, double beta2, double tau) {
+    Hyper h;
+    h.lr = static_cast<float>(lr);
+    h.b1 = static_cast<float>(beta1);
+    h.omb1 = static_cast<float>(1.0 - beta1);
+    h.b2 = static_cast<float>(beta2);
+    h.omb2 = static_cast<float>(1.0 - beta2);
+    h.tau = static_cast<float>(tau);
+    return h;
+}
+
+template <typename T>
+int mean_dispatch(const T* const* x, int K, T* g, size_t n, hipStream_t st) {
+    if (!x || !g || K <= 0) return FA_ERR_INVALID;
+    if (!aligned_to(g, sizeof(T))) return FA_ERR_ALIGN;
+    for (int k = 0; k < K; ++k) {
+        if (!x[k]) return FA_ERR_INVALID;
+        if (!aligned_to(x[k], sizeof(T))) return FA_ERR_ALIGN;
+    }
+    if (n == 0) return FA_OK;
+    const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
+    for (size_t off = 0; off < n; off += kSegment) {
+        size_t len = (n - off < kSegment) ? n - off : kSegment;
+        for (int ch = 0; ch < chunks; ++ch) {
+            MeanArgs<T> a;
+            memset(&a, 0, sizeof(a));
+            const int k0 = ch * FA_KCHUNK;
+            a.K = (K - k0 < FA_KCHUNK) ? K - k0 : FA_KCHUNK;
+            for (int k = 0; k < a.K; ++k) a.x[k] = x[k0 + k] + off;
+            a.g = g + off;
+            a.sum_in = (ch == 0) ? nullptr : g + off;
+            a.n = static_cast<unsigned>(len);
+            a.last = (ch == chunks - 1);
+            a.Kall = static_cast<float>(K);
+            hipLaunchKernelGGL((mean_kernel<T>), dim3(grid_for(len)), dim3(kThreads), 0, st, a);
+            int rc = launch_status();
+            if (rc != FA_OK) return rc;
+        }
+    }
+    return FA_OK;
+}
+
+// Splits [0, n) into <= kSegment pieces and, when every pointer is 16-byte aligned, each piece
+// into a 128-bit body and a scalar tail; `fn(off, count, vec)` launches one kernel.
+template <typename F>
+int for_each_range(size_t n, bool a16, F fn) {
+    for (size_t off = 0; off < n; off += kSegment) {
+        size_t len = (n - off < kSegment) ? n - off : kSegment;
+        size_t body = a16 ? (len & ~size_t(3)) : 0;
+        if (body) {
+            int rc = fn(off, body / 4, true);
+            if (rc != FA_OK) return rc;
+        }
+        if (len > body) {
+            int rc = fn(off + body, len - body, false);
+            if (rc != FA_OK) return rc;
+        }
+    }
+    return FA_OK;
+}
+
+template <typename T>
+int accum_raw_dispatch(const T* x, T* step, int first, size_t n, hipStream_t st) {
+    if (!x || !step) return FA_ERR_INVALID;
+    if (!aligned_to(x, sizeof(T)) || !aligned_to(step, sizeof(T))) return FA_ERR_ALIGN;
+    for (size_t off = 0; off < n; off += kSegment) {
+        size_t len = (n - off < kSegment) ? n - off : kSegment;
+        hipLaunchKernelGGL((accum_raw_kernel<T>), dim3(grid_for(len)), dim3(kThreads), 0, st,
+                           x + off, step + off, first, static_cast<unsigned>(len));
+        int rc = launch_status();
+        if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
+}
+
+template <typename T>
+int flush_mean_dispatch(T* g, const T* step, int K, size_t n, hipStream_t st) {
+    if (!g || !step || K <= 0) return FA_ERR_INVALID;
+    if (!aligned_to(g, sizeof(T)) || !aligned_to(step, sizeof(T))) return FA_ERR_ALIGN;
+    for (size_t off = 0; off < n; off += kSegment) {
+        size_t len = (n - off < kSegment) ? n - off : kSegment;
+        hipLaunchKernelGGL((flush_mean_kernel<T>), dim3(grid_for(len)), dim3(kThreads), 0, st,
+                           g + off, step + off, static_cast<float>(K), static_cast<unsigned>(len));
+        int rc = launch_status();
+        if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
+}
+
+template <int MODE>
+int async_mix_mode(const float* x, float alpha, float* g, float* step_out, size_t n, bool a16,
+                   hipStream_t st) {
+    return for_each_range(n, a16, [&](size_t off, size_t cnt, bool vec) {
+        float* so = step_out ? step_out + off : nullptr;
+        if (vec)
+            hipLaunchKernelGGL((async_mix_kernel<4, MODE>), dim3(grid_for(cnt)), dim3(kThreads), 0,
+                               st, x + off, alpha, g + off, so, static_cast<unsigned>(cnt));
+        else
+            hipLaunchKernelGGL((async_mix_kernel<1, MODE>), dim3(grid_for(cnt)), dim3(kThreads), 0,
+                               st, x + off, alpha, g + off, so, static_cast<unsigned>(cnt));
+        return launch_status();
+    });
+}
+
+template <int MODE, bool FLUSH>
+int buff_accum_mode(const float* x, float alpha, float* g, float* step, int first, size_t n,
+                    bool a16, hipStream_t st) {
+    return for_each_range(n, a16, [&](size_t off, size_t cnt, bool vec) {
+        if (vec)
+            hipLaunchKernelGGL((buff_accum_kernel<4, MODE, FLUSH>), dim3(grid_for(cnt)),
+                               dim3(kThreads), 0, st, x + off, alpha, g + off, step + off, first,
+                               static_cast<unsigned>(cnt));
+        else
+            hipLaunchKernelGGL((buff_accum_kernel<1, MODE, FLUSH>), dim3(grid_for(cnt)),
+                               dim3(kThreads), 0, st, x + off, alpha, g + off, step + off, first,
+                               static_cast<unsigned>(cnt));
+        return launch_status();
+    });
+}
+
+template <bool FLUSH>
+int buff_accum_dispatch(const float* x, double alpha_t, int gradient_based, float* g, float* step,
+                        int first, size_t n, hipStream_t st) {
+    if (!x || !g || !step) return FA_ERR_INVALID;
+    if (!aligned_to(x, 4) || !aligned_to(g, 4) || !aligned_to(step, 4)) return FA_ERR_ALIGN;
+    const bool a16 = aligned16(x) && aligned16(g) && aligned16(step);
+    const float alpha = static_cast<float>(alpha_t);
+    if (gradient_based) return buff_accum_mode<2, FLUSH>(x, alpha, g, step, first, n, a16, st);
+    return buff_accum_mode<0, FLUSH>(x, alpha, g, step, first, n, a16, st);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+
+extern "C" {
+
+int fa_version(void) { return 100; }
+
+int fa_kchunk(void) { return FA_KCHUNK; }
+
+int fa_tune(int vpt, int unroll, int nt, int max_blocks) {
+    if (vpt != 1 && vpt != 2 && vpt != 4) return FA_ERR_INVALID;
+    if (unroll != 4 && unroll != 8 && unroll != 16) return FA_ERR_INVALID;
+    g_shape.vpt = vpt;
+    g_shape.unroll = unroll;
+    g_shape.nt = nt ? 1 : 0;
+    g_shape.max_blocks = max_blocks > 0 ? max_blocks : kMaxBlocks;
+    return FA_OK;
+}
+
+const char* fa_error_string(int code) {
+    switch (code) {
+        case FA_OK: return "ok";
+        case FA_ERR_INVALID: return "invalid argument";
+        case FA_ERR_ALIGN: return "buffer not aligned to its element size";
+        case FA_ERR_WORKSPACE: return "K > FA_KCHUNK needs a step workspace";
+    }
+    if (code <= FA_ERR_HIP) return hipGetErrorString(static_cast<hipError_t>(FA_ERR_HIP - code));
+    return "unknown error";
+}
+
+int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+                  size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                  float* step_out, float* step_ws, fa_stream_t stream) {
+    ReduceCall c{x, w, K, g, nullptr, m, v, n, opt, make_hyper(lr, beta1, beta2, tau),
+                 step_out, step_ws, 1};
+    return reduce_dispatch(c, as_stream(stream));
+}
+
+int fa_reduce_apply(const float* const* x, const double* w, int K, float* g, size_t n,
+                    float* step_ws, fa_stream_t stream) {
+    return fa_reduce_opt(x, w, K, g, nullptr, nullptr, n, FA_OPT_NONE, 0, 0, 0, 0, nullptr,
+                         step_ws, stream);
+}
+
+int fa_reduce_opt_slab(const float* slab, size_t stride, const double* w, int K, float* g,
+                       float* m, float* v, size_t n, int opt, double lr, double beta1,
+                       double beta2, double tau, float* step_out, float* step_ws,
+                       fa_stream_t stream) {
+    if (!slab || K <= 0) return FA_ERR_INVALID;
+    std::vector<const float*> x(static_cast<size_t>(K));
+    for (int k = 0; k < K; ++k) x[static_cast<size_t>(k)] = slab + static_cast<size_t>(k) * stride;
+    return fa_reduce_opt(x.data(), w, K, g, m, v, n, opt, lr, beta1, beta2, tau, step_out, step_ws,
+                         stream);
+}
+
+int fa_reduce_step(const float* const* x, const double* w, int K, const float* g, float* step_out,
+                   size_t n, fa_stream_t stream) {
+    ReduceCall c{x, w, K, nullptr, g, nullptr, nullptr, n, FA_OPT_NONE, make_hyper(0, 0, 0, 0),
+                 step_out, nullptr, 0};
+    return reduce_dispatch(c, as_stream(stream));
+}
+
+int fa_apply_step(float* g, const float* step, size_t n, fa_stream_t stream) {
+    if (!g || !step) return FA_ERR_INVALID;
+    if (!aligned_to(g, 4) || !aligned_to(step, 4)) return FA_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    return for_each_range(n, aligned16(g) && aligned16(step), [&](size_t off, size_t cnt, bool vec) {
+        if (vec)
+            hipLaunchKernelGGL((apply_kernel<4>), dim3(grid_for(cnt)), dim3(kThreads), 0, st,
+                               g + off, step + off, static_cast<unsigned>(cnt));
+        else
+            hipLaunchKernelGGL((apply_kernel<1>), dim3(grid_for(cnt)), dim3(kThreads), 0, st,
+                               g + off, step + off, static_cast<unsigned>(cnt));
+        return launch_status();
+    });
+}
+
+int fa_mean_f32(const float* const* x, int K, float* g, size_t n, fa_stream_t stream) {
+    return mean_dispatch<float>(x, K, g, n, as_stream(stream));
+}
+int fa_mean_i64(const int64_t* const* x, int K, int64_t* g, size_t n, fa_stream_t stream) {
+    return mean_dispatch<int64_t>(x, K, g, n, as_stream(stream));
+}
+int fa_mean_i32(const int32_t* const* x, int K, int32_t* g, size_t n, fa_stream_t stream) {
+    return mean_dispatch<int32_t>(x, K, g, n, as_stream(stream));
+}
+
+int fa_async_mix(const float* x, double alpha_t, int gradient_based, int sub_form, float* g,
+                 float* step_out, size_t n, fa_stream_t stream) {
+    if (!x || !g) return FA_ERR_INVALID;
+    if (!aligned_to(x, 4) || !aligned_to(g, 4) || (step_out && !aligned_to(step_out, 4)))
+        return FA_ERR_ALIGN;
+    const bool a16 = aligned16(x) && aligned16(g) && (!step_out || aligned16(step_out));
+    const float alpha = static_cast<float>(alpha_t);
+    hipStream_t st = as_stream(stream);
+    if (!gradient_based) return async_mix_mode<0>(x, alpha, g, step_out, n, a16, st);
+    if (sub_form) return async_mix_mode<1>(x, alpha, g, step_out, n, a16, st);
+    return async_mix_mode<2>(x, alpha, g, step_out, n, a16, st);
+}
+
+int fa_buff_accum(const float* x, double alpha_t, int gradient_based, const float* g, float* step,
+                  int first, size_t n, fa_stream_t stream) {
+    return buff_accum_dispatch<false>(x, alpha_t, gradient_based, const_cast<float*>(g), step,
+                                      first, n, as_stream(stream));
+}
+
+int fa_buff_accum_flush(const float* x, double alpha_t, int gradient_based, float* g, float* step,
+                        int first, size_t n, fa_stream_t stream) {
+    return buff_accum_dispatch<true>(x, alpha_t, gradient_based, g, step, first, n,
+                                     as_stream(stream));
+}
+
+int fa_buff_accum_raw_f32(const float* x, float* step, int first, size_t n, fa_stream_t stream) {
+    return accum_raw_dispatch<float>(x, step, first, n, as_stream(stream));
+}
+int fa_buff_accum_raw_i64(const int64_t* x, int64_t* step, int first, size_t n,
+                          fa_stream_t stream) {
+    return accum_raw_dispatch<int64_t>(x, step, first, n, as_stream(stream));
+}
+int fa_buff_accum_raw_i32(const int32_t* x, int32_t* step, int first, size_t n,
+                          fa_stream_t stream) {
+    return accum_raw_dispatch<int32_t>(x, step, first, n, as_stream(stream));
+}
+
+int fa_buff_flush_mean_f32(float* g, const float* step, int K, size_t n, fa_stream_t stream) {
+    return flush_mean_dispatch<float>(g, step, K, n, as_stream(stream));
+}
+int fa_buff_flush_mean_i64(int64_t* g, const int64_t* step, int K, size_t n, fa_stream_t stream) {
+    return flush_mean_dispatch<int64_t>(g, step, K, n, as_stream(stream));
+}
+int fa_buff_flush_mean_i32(int32_t* g, const int32_t* step, int K, size_t n, fa_stream_t stream) {
+    return flush_mean_dispatch<int32_t>(g, step, K, n, as_stream(stream));
+}
+
+int fa_fill_f32(float* p, float value, size_t n, fa_stream_t stream) {
+    if (!p) return FA_ERR_INVALID;
+    if (!aligned_to(p, 4)) return FA_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    return for_each_range(n, aligned16(p), [&](size_t off, size_t cnt, bool vec) {
+        if (vec)
+            hipLaunchKernelGGL((fill_kernel<4>), dim3(grid_for(cnt)), dim3(kThreads), 0, st,
+                               p + off, value, static_cast<unsigned>(cnt));
+        else
+            hipLaunchKernelGGL((fill_kernel<1>), dim3(grid_for(cnt)), dim3(kThreads), 0, st,
+                               p + off, value, static_cast<unsigned>(cnt));
+        return launch_status();
+    });
+}
+
+int fa_synth_fill(float* p, const float* base, size_t n, uint64_t seed, uint64_t first,
+                  float scale, fa_stream_t stream) {
+    if (!p) return FA_ERR_INVALID;
+    if (!aligned_to(p, 4) || (base && !aligned_to(base, 4))) return FA_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    for (size_t off = 0; off < n; off += kSegment) {
+        size_t len = (n - off < kSegment) ? n - off : kSegment;
+        hipLaunchKernelGGL(synth_kernel, dim3(grid_for(len)), dim3(kThreads), 0, st, p + off,
+                           base ? base + off : nullptr, static_cast<unsigned>(len), seed,
+                           first + off, scale);
+        int rc = launch_status();
+        if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
+}
+
+int fa_pack_host(void* dst, const void* const* src, const size_t* dst_off, const size_t* nbytes,
+                 int T, int threads) {
+    if (!dst || !src || !dst_off || !nbytes || T < 0) return FA_ERR_INVALID;
+    for (int t = 0; t < T; ++t)
+        if (!src[t] && nbytes[t]) return FA_ERR_INVALID;
+    size_t total = 0;
+    for (int t = 0; t < T; ++t) total += nbytes[t];
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    // Byte-balanced split: thread j copies bytes [total*j/threads, total*(j+1)/threads) of the
+    // concatenated payload, so a few large tensors do not serialise the copy.
+    if (threads == 1 || total < (size_t(1) << 20)) {
+        for (int t = 0; t < T; ++t)
+            if (nbytes[t]) memcpy(static_cast<char*>(dst) + dst_off[t], src[t], nbytes[t]);
+        return FA_OK;
+    }
+    auto work = [&](int j) {
+        const size_t lo = total / threads * j + (total % threads) * j / threads;
+        const size_t hi = (j == threads - 1) ? total
+                                             : total / threads * (j + 1) + (total % threads) * (j + 1) / threads;
+        size_t pos = 0;
+        for (int t = 0; t < T && pos < hi; ++t) {
+            const size_t b = pos, e = pos + nbytes[t];
+            pos = e;
+            const size_t s = b > lo ? b : lo, f = e < hi ? e : hi;
+            if (s < f)
+                memcpy(static_cast<char*>(dst) + dst_off[t] + (s - b),
+                       static_cast<const char*>(src[t]) + (s - b), f - s);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(static_cast<size_t>(threads));
+    for (int j = 1; j < threads; ++j) pool.emplace_back(work, j);
+    work(0);
+    for (auto& th : pool) th.join();
+    return FA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+"""Flat-vector operations on device tensors, one function per C-ABI entry point.
+
+Every function enqueues its kernel on the CURRENT torch stream of the tensors' device and
+returns immediately; tensors must be contiguous 1-D device tensors.  PyTorch is only used for
+device memory and streams -- the arithmetic is in ``libappfl_amd.so``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _native as N
+
+OPT_CODES = {
+    "none": N.FA_OPT_NONE,
+    "avgm": N.FA_OPT_AVGM,
+    "adam": N.FA_OPT_ADAM,
+    "yogi": N.FA_OPT_YOGI,
+    "adagrad": N.FA_OPT_ADAGRAD,
+}
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise N.NativeLibraryError("libappfl_amd kernels take device tensors; got a CPU tensor")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _check_rows(x: Sequence[torch.Tensor], n: int, dtype) -> "C.Array":
+    ptrs = []
+    for t in x:
+        if t.numel() < n:
+            raise ValueError(f"client buffer has {t.numel()} elements, need {n}")
+        ptrs.append(_dev(t, dtype))
+    return N.ptr_array(ptrs)
+
+
+def kchunk() -> int:
+    return N.load().fa_kchunk()
+
+
+def tune(vpt: int = 4, unroll: int = 8, nt: int = 1, max_blocks: int = 0) -> None:
+    N.check(N.load().fa_tune(vpt, unroll, nt, max_blocks), "fa_tune")
+
+
+def reduce_opt(x: Sequence[torch.Tensor], w: Sequence[float], g: torch.Tensor,
+               m: Optional[torch.Tensor] = None, v: Optional[torch.Tensor] = None,
+               opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
+               tau: float = 0.0, step_out: Optional[torch.Tensor] = None,
+               step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
+    """Fused weighted step + server optimizer + apply over ``g[:n]`` (fa_reduce_opt)."""
+    n = g.numel() if n is None else n
+    if len(x) != len(w):
+        raise ValueError("one weight per client buffer")
+    for t in (m, v, step_out, step_ws):
+        if t is not None and t.numel() < n:
+            raise ValueError("state / workspace tensor shorter than n")
+    rc = N.load().fa_reduce_opt(
+        _check_rows(x, n, torch.float32), N.double_array([float(t) for t in w]), len(x),
+        _dev(g, torch.float32), _dev(m, torch.float32), _dev(v, torch.float32), n,
+        OPT_CODES[opt], float(lr), float(beta1), float(beta2), float(tau),
+        _dev(step_out, torch.float32), _dev(step_ws, torch.float32), _stream(g))
+    N.check(rc, "fa_reduce_opt")
+
+
+def reduce_opt_slab(slab: torch.Tensor, stride: int, w: Sequence[float], g: torch.Tensor,
+                    m=None, v=None, opt: str = "none", lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
+                    step_out=None, step_ws=None, n: Optional[int] = None) -> None:
+    """Same with the K client rows in one slab, row k at ``slab[k*stride:]``."""
+    n = g.numel() if n is None else n
+    K = len(w)
+    if K < 1 or slab.numel() < (K - 1) * stride + n:
+        raise ValueError("slab too small for K rows")
+    rc = N.load().fa_reduce_opt_slab(
+        _dev(slab, torch.float32), stride, N.double_array([float(t) for t in w]), K,
+        _dev(g, torch.float32), _dev(m, torch.float32), _dev(v, torch.float32), n,
+        OPT_CODES[opt], float(lr), float(beta1), float(beta2), float(tau),
+        _dev(step_out, torch.float32), _dev(step_ws, torch.float32), _stream(g))
+    N.check(rc, "fa_reduce_opt_slab")
+
+
+def reduce_step(x, w, g, step_out, n: Optional[int] = None) -> None:
+    n = g.numel() if n is None else n
+    if step_out.numel() < n:
+        raise ValueError("step_out shorter than n")
+    rc = N.load().fa_reduce_step(_check_rows(x, n, torch.float32),
+                                 N.double_array([float(t) for t in w]), len(x),
+                                 _dev(g, torch.float32), _dev(step_out, torch.float32), n,
+                                 _stream(g))
+    N.check(rc, "fa_reduce_step")
+
+
+def apply_step(g, step, n: Optional[int] = None) -> None:
+    n = g.numel() if n is None else n
+    if step.numel() < n:
+        raise ValueError("step shorter than n")
+    N.check(N.load().fa_apply_step(_dev(g, torch.float32), _dev(step, torch.float32), n,
+                                   _stream(g)), "fa_apply_step")
+
+
+_MEAN = {torch.float32: "fa_mean_f32", torch.int64: "fa_mean_i64", torch.int32: "fa_mean_i32"}
+_RAW = {torch.float32: "fa_buff_accum_raw_f32", torch.int64: "fa_buff_accum_raw_i64",
+        torch.int32: "fa_buff_accum_raw_i32"}
+_FLUSH = {torch.float32: "fa_buff_flush_mean_f32", torch.int64: "fa_buff_flush_mean_i64",
+          torch.int32: "fa_buff_flush_mean_i32"}
+
+
+def mean(x: Sequence[torch.Tensor], g: torch.Tensor, n: Optional[int] = None) -> None:
+    """Plain mean over clients into ``g[:n]`` (f32 / i64 / i32)."""
+    n = g.numel() if n is None else n
+    fn = getattr(N.load(), _MEAN[g.dtype])
+    N.check(fn(_check_rows(x, n, g.dtype), len(x), _dev(g), n, _stream(g)), _MEAN[g.dtype])
+
+
+def async_mix(x, alpha_t: float, g, gradient_based: bool = False, sub_form: bool = True,
+              step_out=None, n: Optional[int] = None) -> None:
+    n = g.numel() if n is None else n
+    if x.numel() < n:
+        raise ValueError("x shorter than n")
+    rc = N.load().fa_async_mix(_dev(x, torch.float32), float(alpha_t), int(bool(gradient_based)),
+                               int(bool(sub_form)), _dev(g, torch.float32),
+                               _dev(step_out, torch.float32), n, _stream(g))
+    N.check(rc, "fa_async_mix")
+
+
+def buff_accum(x, alpha_t: float, g, step, first: bool, gradient_based: bool = False,
+               flush: bool = False, n: Optional[int] = None) -> None:
+    n = g.numel() if n is None else n
+    if x.numel() < n or step.numel() < n:
+        raise ValueError("x / step shorter than n")
+    fn = N.load().fa_buff_accum_flush if flush else N.load().fa_buff_accum
+    rc = fn(_dev(x, torch.float32), float(alpha_t), int(bool(gradient_based)),
+            _dev(g, torch.float32), _dev(step, torch.float32), int(bool(first)), n, _stream(g))
+    N.check(rc, "fa_buff_accum")
+
+
+def buff_accum_raw(x, step, first: bool, n: Optional[int] = None) -> None:
+    n = step.numel() if n is None else n
+    if x.numel() < n:
+        raise ValueError("x shorter than n")
+    fn = getattr(N.load(), _RAW[step.dtype])
+    N.check(fn(_dev(x, step.dtype), _dev(step), int(bool(first)), n, _stream(step)),
+            _RAW[step.dtype])
+
+
+def buff_flush_mean(g, step, K: int, n: Optional[int] = None) -> None:
+    n = g.numel() if n is None else n
+    if step.numel() < n:
+        raise ValueError("step shorter than n")
+    fn = getattr(N.load(), _FLUSH[g.dtype])
+    N.check(fn(_dev(g), _dev(step, g.dtype), int(K), n, _stream(g)), _FLUSH[g.dtype])
+
+
+def fill(p: torch.Tensor, value: float, n: Optional[int] = None) -> None:
+    n = p.numel() if n is None else n
+    N.check(N.load().fa_fill_f32(_dev(p, torch.float32), C.c_float(value), n, _stream(p)),
+            "fa_fill_f32")
+
+
+def synth_fill(p: torch.Tensor, seed: int, first: int = 0, scale: float = 1.0,
+               base: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
+    """Fill ``p[:n]`` with the shared counter-based synthetic update (see fa_synth_fill)."""
+    n = p.numel() if n is None else n
+    if base is not None and base.numel() < n:
+        raise ValueError("base shorter than n")
+    rc = N.load().fa_synth_fill(_dev(p, torch.float32), _dev(base, torch.float32), n,
+                                C.c_uint64(seed), C.c_uint64(first), C.c_float(scale), _stream(p))
+    N.check(rc, "fa_synth_fill")

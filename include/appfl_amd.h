@@ -1,0 +1,184 @@
+/*
+ * appfl_amd.h -- C ABI of libappfl_amd.so: the MI355X (gfx950) kernels behind APPFL's
+ * server-side Aggregator (FedAvg family, server optimizers, FedAsync / FedBuff mixing).
+ *
+ * Every pointer named x / g / m / v / step is DEVICE memory unless the comment says "host".
+ * Nothing here allocates, frees or synchronises: the caller owns every buffer, every call only
+ * enqueues work on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ * returns.  Calls on one stream execute in order; the library keeps no state between calls, so
+ * it is thread-compatible (concurrent calls must use different buffers).
+ *
+ * Arithmetic contract: each documented formula is evaluated as separately rounded IEEE fp32
+ * operations in the written order (no FMA contraction, correctly rounded / and sqrt, denormals
+ * kept), and client contributions are accumulated in client order k = 0..K-1.  That is the op
+ * sequence of the PyTorch CPU code the reference runs, so results are bit-identical to it.
+ * Host scalars arrive as double and are rounded to fp32 once, exactly where PyTorch rounds a
+ * Python float that multiplies an fp32 tensor.
+ *
+ * Return value: FA_OK (0) or a negative code; fa_error_string() names it.
+ *
+ * Paths below are relative to the reference checkout (src/appfl/...).
+ */
+#ifndef APPFL_AMD_H
+#define APPFL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fa_stream_t;
+
+enum {
+    FA_OK = 0,
+    FA_ERR_INVALID = -1,   /* NULL pointer, K <= 0, unknown opt code, ...                */
+    FA_ERR_ALIGN = -2,     /* a buffer is not aligned to its element size                */
+    FA_ERR_WORKSPACE = -3, /* K > FA_KCHUNK needs a step workspace and none was given     */
+    FA_ERR_HIP = -1000     /* FA_ERR_HIP - hipError_t: a HIP runtime call failed          */
+};
+
+/* Clients folded by one kernel launch; more clients run as several launches that carry the
+ * partial step through the caller's workspace (same client order, same bits). */
+#define FA_KCHUNK 128
+
+/* Server optimizer applied to the averaged pseudo-gradient. */
+enum {
+    FA_OPT_NONE = 0,    /* FedAvg:     algorithm/aggregator/fedavg_aggregator.py:276-283      */
+    FA_OPT_AVGM = 1,    /* FedAvgM:    algorithm/aggregator/fedavgm_aggregator.py:48-61       */
+    FA_OPT_ADAM = 2,    /* FedAdam:    algorithm/aggregator/fedadam_aggregator.py:60-99       */
+    FA_OPT_YOGI = 3,    /* FedYogi:    algorithm/aggregator/fedyogi_aggregator.py:60-97       */
+    FA_OPT_ADAGRAD = 4  /* FedAdagrad: algorithm/aggregator/fedadagrad_aggregator.py:59-91    */
+};
+
+int fa_version(void);
+const char* fa_error_string(int code);
+/* Number of clients one launch folds (FA_KCHUNK), for hosts that size workspaces. */
+int fa_kchunk(void);
+/*
+ * Benchmark hook (no counterpart in the reference): selects the launch shape of the 128-bit
+ * reduce kernel -- vectors per thread (1|2|4), clients loaded ahead (4|8|16), non-temporal
+ * client loads (0|1), grid cap (<= 0: default).  Results do not depend on it.  Process-wide;
+ * not synchronised with concurrent calls.
+ */
+int fa_tune(int vpt, int unroll, int nt, int max_blocks);
+
+/*
+ * Weighted FedAvg step fused with the apply and the server-optimizer epilogue.
+ * Replaces FedAvgAggregator.compute_steps + the "global += step" loop
+ * (algorithm/aggregator/fedavg_aggregator.py:322-368 and :276-283) and, for opt != NONE, the
+ * subclass compute_steps bodies listed at the FA_OPT_* codes.  Per element i:
+ *     step = 0;  for k in 0..K-1:  step = step + (x[k][i] - g[i]) * (float)w[k]
+ *     AVGM:    v = v*b1 + step;                         step = v
+ *     ADAM:    m = m*b1 + step*(float)(1-b1);  v = v*b2 + (step*step)*(float)(1-b2)
+ *     YOGI:    m as ADAM;  s2 = step*step;  v = v - (s2*sign(v - s2))*(float)(1-b2)
+ *     ADAGRAD: m as ADAM;  v = v + step*step
+ *     ADAM/YOGI/ADAGRAD:   step = ((float)lr*m) / (sqrt(v) + (float)tau)
+ *     g[i] = g[i] + step
+ * x: HOST array of K device pointers (each n floats); w: HOST array of K client weights.
+ * m, v: moment vectors (n floats each; m unused for AVGM, both unused for NONE -> may be NULL).
+ * step_out: optional (may be NULL) n-float buffer that receives the final step (the value the
+ * reference leaves in self.step before the apply).
+ * step_ws: n-float workspace, only touched when K > FA_KCHUNK (may be NULL otherwise).
+ * Buffers must not overlap except where stated; 16-byte alignment of every buffer selects the
+ * 128-bit path, anything else falls back to a scalar kernel with the same results.
+ */
+int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+                  size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                  float* step_out, float* step_ws, fa_stream_t stream);
+
+/* FedAvg only: fa_reduce_opt with opt = FA_OPT_NONE and no moments. */
+int fa_reduce_apply(const float* const* x, const double* w, int K, float* g, size_t n,
+                    float* step_ws, fa_stream_t stream);
+
+/* Same, for K client rows stored in one slab: x[k] = slab + k * stride (elements). */
+int fa_reduce_opt_slab(const float* slab, size_t stride, const double* w, int K, float* g,
+                       float* m, float* v, size_t n, int opt, double lr, double beta1,
+                       double beta2, double tau, float* step_out, float* step_ws,
+                       fa_stream_t stream);
+
+/*
+ * Step only (no apply, no optimizer): step_out[i] = sum_k (x[k][i] - g[i]) * (float)w[k].
+ * Replaces FedAvgAggregator.compute_steps alone (fedavg_aggregator.py:322-368) for callers
+ * that post-process self.step themselves.
+ */
+int fa_reduce_step(const float* const* x, const double* w, int K, const float* g,
+                   float* step_out, size_t n, fa_stream_t stream);
+
+/* g[i] = g[i] + step[i]  (fedavg_aggregator.py:281-283; fedbuff_aggregator.py:88). */
+int fa_apply_step(float* g, const float* step, size_t n, fa_stream_t stream);
+
+/*
+ * Plain mean of entries that bypass the weighted step (integer tensors, and non-parameter
+ * entries when a model was supplied): fedavg_aggregator.py:285-295 with
+ * misc/memory_utils.py:95-110.   s = 0; for k: s = s + x[k][i];
+ *   f32: g = s / (float)K        i64/i32: g = (int)trunc((float)s / (float)K)
+ */
+int fa_mean_f32(const float* const* x, int K, float* g, size_t n, fa_stream_t stream);
+int fa_mean_i64(const int64_t* const* x, int K, int64_t* g, size_t n, fa_stream_t stream);
+int fa_mean_i32(const int32_t* const* x, int K, int32_t* g, size_t n, fa_stream_t stream);
+
+/*
+ * FedAsync arrival (algorithm/aggregator/fedasync_aggregator.py:243-264 and :156-160).
+ *   gradient_based == 0:  step = (float)alpha_t * (x - g)
+ *   gradient_based == 1:  step = 0 - (float)alpha_t * x      (sub_form == 1, optimize_memory)
+ *                         step = (float)alpha_t * (-x)       (sub_form == 0)
+ *   g = g + step
+ * The two gradient_based forms differ only in the sign of a zero step.
+ * step_out (may be NULL) receives the step.
+ */
+int fa_async_mix(const float* x, double alpha_t, int gradient_based, int sub_form, float* g,
+                 float* step_out, size_t n, fa_stream_t stream);
+
+/*
+ * FedBuff arrival (algorithm/aggregator/fedbuff_aggregator.py:145-158): g stays frozen,
+ *   step = step + (float)alpha_t * (x - g)     or, gradient_based:  step + (float)alpha_t*(-x)
+ * first != 0 treats the incoming step as zero (the buffer was just reset, :116-124).
+ */
+int fa_buff_accum(const float* x, double alpha_t, int gradient_based, const float* g,
+                  float* step, int first, size_t n, fa_stream_t stream);
+/* Same arrival when it fills the buffer: also applies the flush g = g + step
+ * (fedbuff_aggregator.py:75-88) in the same pass; step is left holding the flushed step. */
+int fa_buff_accum_flush(const float* x, double alpha_t, int gradient_based, float* g,
+                        float* step, int first, size_t n, fa_stream_t stream);
+/* Entries FedBuff sums raw (fedbuff_aggregator.py:146-152): step = step + x. */
+int fa_buff_accum_raw_f32(const float* x, float* step, int first, size_t n, fa_stream_t stream);
+int fa_buff_accum_raw_i64(const int64_t* x, int64_t* step, int first, size_t n,
+                          fa_stream_t stream);
+int fa_buff_accum_raw_i32(const int32_t* x, int32_t* step, int first, size_t n,
+                          fa_stream_t stream);
+/* ... and flushes as a mean (fedbuff_aggregator.py:84-86): g = (T)((float)step / (float)K);
+ * for f32 that is g = step / (float)K. */
+int fa_buff_flush_mean_f32(float* g, const float* step, int K, size_t n, fa_stream_t stream);
+int fa_buff_flush_mean_i64(int64_t* g, const int64_t* step, int K, size_t n,
+                           fa_stream_t stream);
+int fa_buff_flush_mean_i32(int32_t* g, const int32_t* step, int K, size_t n,
+                           fa_stream_t stream);
+
+/* p[i] = value: moment initialisation (m = 0, v = (float)(tau**2), fedadam_aggregator.py:45-49). */
+int fa_fill_f32(float* p, float value, size_t n, fa_stream_t stream);
+
+/*
+ * Synthetic client update, generated on the device with the counter-based integer PRNG the
+ * tests and the benchmark share with the CPU oracle (no counterpart in the reference):
+ *   noise(seed, i) = (sum of the four 16-bit fields of splitmix64(seed, i) - 131070) * c
+ *   p[i] = base ? base[i] + scale * noise(seed, first + i) : scale * noise(seed, first + i)
+ * `first` is the global index of p[0], so shards of one vector can be filled independently.
+ */
+int fa_synth_fill(float* p, const float* base, size_t n, uint64_t seed, uint64_t first,
+                  float scale, fa_stream_t stream);
+
+/*
+ * Host-side packing of one client's state dict into a row of a (pinned) staging slab:
+ * for t in 0..T-1: memcpy(dst + dst_off[t], src[t], nbytes[t]), spread over `threads` threads.
+ * All pointers are HOST memory.  Stands where the reference materialises per-tensor CPU
+ * tensors (agent/server.py:505-525) before the aggregator sees them.
+ */
+int fa_pack_host(void* dst, const void* const* src, const size_t* dst_off, const size_t* nbytes,
+                 int T, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APPFL_AMD_H */

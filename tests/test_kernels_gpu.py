@@ -1,0 +1,272 @@
+"""HIP kernels (through the C ABI) against the C oracle on the same seeded inputs: bit-exact."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+HP = dict(lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
+HP_YOGI = dict(lr=0.01, beta1=0.9, beta2=0.99, tau=1e-3)
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else a.dtype)
+
+
+def assert_bits(got, want, what):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    bad = np.nonzero(bits(got) != bits(want))[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {want.size} differ, first at {bad[:5]}: " \
+                          f"{got[bad[:5]]} vs {want[bad[:5]]}"
+
+
+def make_clients(n, K, seed=7, spike=True):
+    base = O.synth_fill(n, seed, scale=0.05)
+    xs = [O.synth_fill(n, 1000 + k, scale=0.01, base=base) for k in range(K)]
+    if spike and n > 16:
+        xs[0][3] = base[3]          # zero difference
+        xs[K - 1][5] = 1e30         # huge
+        xs[0][7] = -0.0
+        base[9] = 0.0
+        for x in xs:
+            x[9] = 0.0              # all-zero column: Yogi sign(0), step 0
+        xs[0][11] = 1e-41           # denormal input
+    return base, xs
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 257, 1000003])
+@pytest.mark.parametrize("K", [1, 2, 7, 9, 100])
+def test_reduce_apply_matches_oracle(n, K):
+    from appfl_amd import ops
+    base, xs = make_clients(n, K)
+    w = [(3 + 2 * k) / sum(3 + 2 * j for j in range(K)) for k in range(K)]
+    g_ref = base.copy()
+    step_ref = np.empty_like(base)
+    O.reduce_opt(xs, w, g_ref, step_out=step_ref)
+    g = dev(base)
+    step = torch.empty_like(g)
+    ops.reduce_opt([dev(x) for x in xs], w, g, step_out=step)
+    assert_bits(step, step_ref, "step")
+    assert_bits(g, g_ref, "g")
+
+
+@pytest.mark.parametrize("opt,hp", [("avgm", HP), ("adam", HP), ("yogi", HP_YOGI), ("adagrad", HP)])
+@pytest.mark.parametrize("n", [5, 4099])
+def test_optimizer_rounds_match_oracle(opt, hp, n):
+    """Three consecutive rounds so m / v state carries over; K changes between rounds."""
+    from appfl_amd import ops
+    code = {"avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI, "adagrad": O.OPT_ADAGRAD}[opt]
+    base, _ = make_clients(n, 1)
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v0 = np.float32(0.0) if opt == "avgm" else np.float32(hp["tau"] ** 2)
+    v_ref = np.full_like(base, v0)
+    g, m, v = dev(base), dev(m_ref), dev(v_ref)
+    for rnd, K in enumerate([4, 7, 2]):
+        xs = [O.synth_fill(n, 50 * rnd + k, scale=0.02, base=g_ref) for k in range(K)]
+        if n > 4:
+            for x in xs:
+                x[2] = g_ref[2]     # exact zero pseudo-gradient
+        w = [1.0 / K] * K
+        O.reduce_opt(xs, w, g_ref, m_ref, v_ref, code, **hp)
+        ops.reduce_opt([dev(x) for x in xs], w, g, m, v, opt, **hp)
+        assert_bits(v, v_ref, f"v round {rnd}")
+        if opt != "avgm":
+            assert_bits(m, m_ref, f"m round {rnd}")
+        assert_bits(g, g_ref, f"g round {rnd}")
+
+
+def test_many_clients_use_workspace():
+    """K > FA_KCHUNK runs as several launches carrying the partial step; same bits."""
+    from appfl_amd import ops
+    n, K = 1027, 2 * ops.kchunk() + 3
+    base, xs = make_clients(n, K, spike=False)
+    w = [1.0 / K] * K
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v_ref = np.full_like(base, np.float32(1e-6))
+    O.reduce_opt(xs, w, g_ref, m_ref, v_ref, O.OPT_ADAM, **HP)
+    g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, np.float32(1e-6)))
+    dx = [dev(x) for x in xs]
+    with pytest.raises(Exception):
+        ops.reduce_opt(dx, w, g, m, v, "adam", **HP)
+    ops.reduce_opt(dx, w, g, m, v, "adam", step_ws=torch.empty_like(g), **HP)
+    assert_bits(g, g_ref, "g")
+    assert_bits(m, m_ref, "m")
+    assert_bits(v, v_ref, "v")
+
+
+def test_unaligned_buffers_take_scalar_path():
+    from appfl_amd import ops
+    n, K = 1001, 5
+    base, xs = make_clients(n, K)
+    w = [1.0 / K] * K
+    g_ref = base.copy()
+    O.reduce_opt(xs, w, g_ref)
+    gbuf = torch.zeros(n + 1, device="cuda")
+    g = gbuf[1:]
+    g.copy_(dev(base))
+    dx = []
+    for k, x in enumerate(xs):
+        b = torch.zeros(n + 3, device="cuda")
+        v = b[k % 3:k % 3 + n]
+        v.copy_(dev(x))
+        dx.append(v)
+    ops.reduce_opt(dx, w, g)
+    assert_bits(g, g_ref, "g")
+
+
+def test_reduce_step_and_apply():
+    from appfl_amd import ops
+    n, K = 70001, 6
+    base, xs = make_clients(n, K)
+    w = [1.0 / K] * K
+    step_ref = np.empty_like(base)
+    O.reduce_step(xs, w, base, step_ref)
+    g = dev(base)
+    step = torch.empty_like(g)
+    ops.reduce_step([dev(x) for x in xs], w, g, step)
+    assert_bits(step, step_ref, "step")
+    assert_bits(g, base, "g untouched")
+    g_ref = base.copy()
+    O.apply_step(g_ref, step_ref)
+    ops.apply_step(g, step)
+    assert_bits(g, g_ref, "g")
+
+
+def test_slab_entry_point():
+    from appfl_amd import ops
+    n, K, stride = 5003, 4, 5008
+    base, xs = make_clients(n, K)
+    w = [0.1, 0.2, 0.3, 0.4]
+    g_ref = base.copy()
+    O.reduce_opt(xs, w, g_ref)
+    slab = torch.zeros(K * stride, device="cuda")
+    for k, x in enumerate(xs):
+        slab[k * stride:k * stride + n].copy_(dev(x))
+    g = dev(base)
+    ops.reduce_opt_slab(slab, stride, w, g)
+    assert_bits(g, g_ref, "g")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int64, np.int32])
+@pytest.mark.parametrize("K", [1, 3, 4, 7, 130])
+def test_plain_mean(dtype, K):
+    from appfl_amd import ops
+    n = 1001
+    rng = np.random.default_rng(K)
+    if dtype == np.float32:
+        xs = [O.synth_fill(n, 10 + k, scale=1.0) for k in range(K)]
+    else:
+        xs = [rng.integers(-1000, 1000, n).astype(dtype) for _ in range(K)]
+        xs[0][:3] = [6, 7, -7]
+        for x in xs[1:]:
+            x[:3] = 0
+    g_ref = np.zeros(n, dtype)
+    O.mean(xs, g_ref)
+    g = torch.zeros(n, dtype=getattr(torch, np.dtype(dtype).name), device="cuda")
+    ops.mean([dev(x) for x in xs], g)
+    assert_bits(g, g_ref, "mean")
+
+
+@pytest.mark.parametrize("gradient_based,sub_form", [(False, True), (True, True), (True, False)])
+def test_async_mix(gradient_based, sub_form):
+    from appfl_amd import ops
+    n = 100003
+    base, xs = make_clients(n, 3)
+    g_ref = base.copy()
+    g = dev(base)
+    for k, alpha in enumerate([0.9 * 0.25, 0.9 * 2 ** -0.5 * 0.25, 0.9 / 31.0]):
+        step_ref = np.empty_like(base)
+        O.async_mix(xs[k], alpha, gradient_based, sub_form, g_ref, step_ref)
+        step = torch.empty_like(g)
+        ops.async_mix(dev(xs[k]), alpha, g, gradient_based, sub_form, step_out=step)
+        assert_bits(step, step_ref, f"step {k}")
+        assert_bits(g, g_ref, f"g {k}")
+
+
+@pytest.mark.parametrize("gradient_based", [False, True])
+def test_buff_accumulate_and_flush(gradient_based):
+    from appfl_amd import ops
+    n, K = 50001, 3
+    base, xs = make_clients(n, K)
+    g_ref, step_ref = base.copy(), np.full_like(base, 123.0)
+    g, step = dev(base), torch.full((n,), 123.0, device="cuda")
+    alphas = [0.3, 0.9 * 3 ** -0.5 / 4, 0.225]
+    for k in range(K):
+        last = k == K - 1
+        O.buff_accum(xs[k], alphas[k], gradient_based, g_ref, step_ref, k == 0, last)
+        ops.buff_accum(dev(xs[k]), alphas[k], g, step, k == 0, gradient_based, flush=last)
+        assert_bits(step, step_ref, f"step {k}")
+        assert_bits(g, g_ref, f"g {k}")
+    # unfused flush gives the same bits
+    g2_ref, s2_ref = base.copy(), np.zeros_like(base)
+    g2, s2 = dev(base), torch.zeros(n, device="cuda")
+    for k in range(K):
+        O.buff_accum(xs[k], alphas[k], gradient_based, g2_ref, s2_ref, k == 0, False)
+        ops.buff_accum(dev(xs[k]), alphas[k], g2, s2, k == 0, gradient_based)
+    O.apply_step(g2_ref, s2_ref)
+    ops.apply_step(g2, s2)
+    assert_bits(g2, g_ref, "unfused flush")
+    assert_bits(g2, g2_ref, "unfused flush vs oracle")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int64, np.int32])
+def test_buff_raw_entries(dtype):
+    from appfl_amd import ops
+    n, K = 1001, 3
+    rng = np.random.default_rng(3)
+    xs = [(rng.integers(-50, 50, n)).astype(dtype) for _ in range(K)]
+    xs[0][:2], xs[1][:2], xs[2][:2] = [4, -4], [7, -7], [0, 0]
+    tdt = getattr(torch, np.dtype(dtype).name)
+    step_ref = np.full(n, 9, dtype)
+    step = torch.full((n,), 9, dtype=tdt, device="cuda")
+    for k in range(K):
+        O.buff_accum_raw(xs[k], step_ref, k == 0)
+        ops.buff_accum_raw(dev(xs[k]), step, k == 0)
+    assert_bits(step, step_ref, "raw step")
+    g_ref = np.zeros(n, dtype)
+    g = torch.zeros(n, dtype=tdt, device="cuda")
+    O.buff_flush_mean(g_ref, step_ref, 2)
+    ops.buff_flush_mean(g, step, 2)
+    assert_bits(g, g_ref, "flush mean")
+
+
+def test_synth_fill_matches_host_generator():
+    from appfl_amd import ops
+    n = 100001
+    base = O.synth_fill(n, 7, first=5, scale=0.05)
+    want = O.synth_fill(n, 1234, first=99, scale=0.01, base=base)
+    b = torch.empty(n, device="cuda")
+    ops.synth_fill(b, 7, first=5, scale=0.05)
+    assert_bits(b, base, "base")
+    p = torch.empty(n, device="cuda")
+    ops.synth_fill(p, 1234, first=99, scale=0.01, base=b)
+    assert_bits(p, want, "update")
+    assert abs(float(np.std(O.synth_fill(n, 1))) - 1.0) < 0.02
+
+
+def test_every_launch_shape_gives_the_same_bits():
+    from appfl_amd import ops
+    n, K = 300007, 19
+    base, xs = make_clients(n, K)
+    w = [1.0 / K] * K
+    g_ref, m_ref, v_ref = base.copy(), np.zeros_like(base), np.full_like(base, np.float32(1e-6))
+    O.reduce_opt(xs, w, g_ref, m_ref, v_ref, O.OPT_ADAM, **HP)
+    dx = [dev(x) for x in xs]
+    try:
+        for vpt in (1, 2, 4):
+            for unroll in (4, 8, 16):
+                for nt in (0, 1):
+                    ops.tune(vpt, unroll, nt, 64)
+                    g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, np.float32(1e-6)))
+                    ops.reduce_opt(dx, w, g, m, v, "adam", **HP)
+                    assert_bits(g, g_ref, f"g vpt={vpt} u={unroll} nt={nt}")
+                    assert_bits(v, v_ref, f"v vpt={vpt} u={unroll} nt={nt}")
+    finally:
+        ops.tune()
