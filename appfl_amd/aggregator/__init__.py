@@ -1,0 +1,17 @@
+"""Device aggregators under the names `appfl.algorithm.aggregator` uses for the CPU ones."""
+
+from .base_aggregator import BaseAggregator
+from .fedavg_aggregator import (FedAdagradAggregator, FedAdamAggregator, FedAvgAggregator,
+                                FedAvgMAggregator, FedYogiAggregator)
+from .fedasync_aggregator import FedAsyncAggregator, FedBuffAggregator
+
+__all__ = [
+    "BaseAggregator",
+    "FedAvgAggregator",
+    "FedAvgMAggregator",
+    "FedAdamAggregator",
+    "FedYogiAggregator",
+    "FedAdagradAggregator",
+    "FedAsyncAggregator",
+    "FedBuffAggregator",
+]

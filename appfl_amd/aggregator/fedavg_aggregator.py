@@ -1,0 +1,339 @@
+"""FedAvg-family aggregators with the global state, the server-optimizer moments and the K
+staged client updates resident in HBM.
+
+Drop-in for the reference's classes of the same names (constructor, `aggregate`,
+`get_parameters`, `set_client_sample_size`, `set_model_chunk_size`, `compute_steps`):
+
+* algorithm/aggregator/fedavg_aggregator.py:17-404
+* algorithm/aggregator/fedavgm_aggregator.py:9-75
+* algorithm/aggregator/fedadam_aggregator.py:9-133
+* algorithm/aggregator/fedyogi_aggregator.py:9-132
+* algorithm/aggregator/fedadagrad_aggregator.py:9-118
+
+Inputs are the scheduler's CPU (or device) state dicts, outputs are fresh CPU tensors.  One
+`aggregate` call = pack + upload the K clients, ONE fused kernel over the weighted entries
+(weighted step, optimizer, apply), small mean kernels for the other entries, one download.
+
+Deliberate differences from the reference, none of which changes a returned value:
+`global_state`, `step`, `m_vector`, `v_vector` hold DEVICE tensors (views of flat vectors);
+client tensors are never mutated; `optimize_memory` is accepted and ignored (both settings of
+the reference compute the same values).
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, OrderedDict, Union
+
+import torch
+
+from .. import ops
+from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout, split_names_by_size
+from ..staging import ClientSlab
+from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_require,
+                              resolve_device)
+
+
+def _native(fn):
+    """Marks a compute_steps implementation of this package (a user override lacks the mark and
+    switches `aggregate` to the un-fused compute_steps -> apply sequence)."""
+    fn._appfl_amd_native = True
+    return fn
+
+
+class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
+    """
+    :param `model`: optional model; with it, entries that are not `named_parameters` (batch-norm
+        statistics) take the plain mean and `get_parameters` works before the first round.
+    :param `aggregator_configs`: `aggregator_kwargs` of the server configuration.
+    :param `logger`: optional logger (`.info` / `.warning`).
+    """
+
+    _OPT = "none"
+
+    def __init__(self, model: Optional[torch.nn.Module] = None, aggregator_configs: Any = None,
+                 logger: Optional[Any] = None):
+        self.model = model
+        self.logger = logger
+        self.aggregator_configs = aggregator_configs if aggregator_configs is not None else {}
+        self.client_weights_mode = cfg_get(self.aggregator_configs, "client_weights_mode", "equal")
+        self.optimize_memory = cfg_get(self.aggregator_configs, "optimize_memory", True)
+        if self.model is not None:
+            self.named_parameters = {name for name, _ in self.model.named_parameters()}
+        else:
+            self.named_parameters = None
+        self.step: Dict[str, torch.Tensor] = {}
+        self.model_chunk_size = None
+        self.device = resolve_device(self.aggregator_configs)
+        self._layout: Optional[Layout] = None
+        self._flats: Optional[Dict[str, torch.Tensor]] = None      # global state
+        self._slab: Optional[ClientSlab] = None
+        self._m: Optional[torch.Tensor] = None
+        self._v: Optional[torch.Tensor] = None
+        self._step_flat: Optional[torch.Tensor] = None
+        self._staged_for = None
+        self._init_lock()
+
+    # -- attributes the reference exposes -------------------------------------------------------
+    @property
+    def global_state(self) -> Optional[Dict[str, torch.Tensor]]:
+        """{name: device tensor} views of the flat global state (None before the first round)."""
+        if self._layout is None:
+            return None
+        return self._layout.views(self._flats)
+
+    def _moment_views(self, flat) -> Dict[str, torch.Tensor]:
+        if flat is None:
+            return {}
+        return {e.name: flat[e.offset:e.offset + e.numel].view(e.shape)
+                for e in self._layout.entries if e.cls == STEP}
+
+    @property
+    def m_vector(self) -> Dict[str, torch.Tensor]:
+        return self._moment_views(self._m)
+
+    @property
+    def v_vector(self) -> Dict[str, torch.Tensor]:
+        return self._moment_views(self._v)
+
+    def set_model_chunk_size(self, chunk_size: int):
+        """Chunk size in bytes for chunked `get_parameters` (set by the gRPC communicator)."""
+        self.model_chunk_size = chunk_size
+
+    # -- get_parameters: fedavg_aggregator.py:67-148 ---------------------------------------------
+    def get_parameters(self, **kwargs) -> Union[Dict, tuple]:
+        with self._lock:
+            request_chunked = kwargs.get("_request_chunked", False)
+            requested_chunk_id = kwargs.get("_chunk_id", None)
+            if self.model_chunk_size is not None and (request_chunked or requested_chunk_id is not None):
+                if self._layout is None:
+                    if self.model is None:
+                        raise ValueError("Model is not provided to the aggregator.")
+                    source = self.model.state_dict()
+                else:
+                    source = None
+                sizes = ({k: v.numel() * v.element_size() for k, v in source.items()}
+                         if source is not None else
+                         {e.name: e.numel * torch.empty((), dtype=e.dtype).element_size()
+                          for e in self._layout.entries})
+                if sum(sizes.values()) > self.model_chunk_size:
+                    chunks = split_names_by_size(sizes, self.model_chunk_size)
+                    chunk_idx = requested_chunk_id if requested_chunk_id is not None else 0
+                    if requested_chunk_id is None and self.logger:
+                        self.logger.info(
+                            f"GetGlobalModel: Model size {sum(sizes.values()) / 2**20:.2f} MB will "
+                            f"be sent in {len(chunks)} chunks")
+                    keys = chunks[chunk_idx]
+                    if source is not None:
+                        with torch.no_grad():
+                            result = {k: source[k].clone().detach() for k in keys}
+                    else:
+                        result = self._download(keys)
+                    meta = {"_chunk_idx": chunk_idx, "_total_chunks": len(chunks),
+                            "_chunk_keys": keys}
+                    return (result, meta)
+            if self._layout is None:
+                if self.model is None:
+                    raise ValueError("Model is not provided to the aggregator.")
+                with torch.no_grad():
+                    return {k: v.clone().detach() for k, v in self.model.state_dict().items()}
+            return self._download()
+
+    # -- state ------------------------------------------------------------------------------------
+    def _init_global_state(self, first_model: Dict[str, torch.Tensor]):
+        """fedavg_aggregator.py:228-271: the model's entries for the names the first client sent,
+        or (no model) the first client's tensors."""
+        if self.model is not None:
+            model_state = self.model.state_dict()
+            init = {n: model_state[n] for n in first_model if n in model_state}
+        else:
+            init = dict(first_model)
+        self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
+                              self.named_parameters)
+        self._flats = self._layout.alloc_state(self.device)
+        with torch.no_grad():
+            for n, t in init.items():
+                self._layout.view(self._flats, n).copy_(t.detach())
+        self._slab = ClientSlab(self._layout, self.device)
+
+    def _download(self, names=None) -> Dict[str, torch.Tensor]:
+        """Fresh CPU copy of the global state: one D2H copy per dtype, entries are views of it."""
+        lay = self._layout
+        if names is not None:
+            return {n: lay.view(self._flats, n).cpu() for n in names if n in lay.by_name}
+        host = {}
+        for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
+            if n:
+                host[key] = self._flats[key][:n].cpu()
+            else:
+                host[key] = torch.empty(0, dtype=self._flats[key].dtype)
+        return lay.views(host)
+
+    def _client_weights(self, local_models) -> list:
+        """fedavg_aggregator.py:343-358."""
+        sizes = getattr(self, "client_sample_size", None) or {}
+        total = sum(sizes[cid] for cid in local_models if cid in sizes)
+        out = []
+        for cid in local_models:
+            if self.client_weights_mode == "sample_size" and cid in sizes and total > 0:
+                out.append(sizes[cid] / total)
+            else:
+                out.append(1.0 / len(local_models))
+        return out
+
+    def _stage(self, local_models) -> None:
+        """Pack and upload every client's state dict into the device slab (client order =
+        dict order = arrival order, which is the reduction order)."""
+        if self._staged_for is local_models:
+            return
+        K = len(local_models)
+        self._slab.reserve(K)
+        self._slab.begin_round()
+        for k, model in enumerate(local_models.values()):
+            self._slab.upload(k, model, fill_missing_from=self._flats["f32"])
+        self._slab.end_round()
+        self._staged_for = local_models
+
+    def _hyper(self) -> Dict[str, float]:
+        return {}
+
+    def _ensure_moments(self) -> None:
+        """Subclasses allocate m / v on the first round (e.g. fedadam_aggregator.py:41-50)."""
+
+    def _rows(self, K: int, byte_offset: int):
+        return [self._slab.row_ptr(k) + byte_offset for k in range(K)]
+
+    # -- compute_steps: fedavg_aggregator.py:322-368 ------------------------------------------------
+    @_native
+    def compute_steps(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict]]):
+        """Averaged pseudo-gradient of the weighted entries into `self.step` (device views)."""
+        with self._lock:
+            self._stage(local_models)
+            lay = self._layout
+            n = lay.count[STEP]
+            if self._step_flat is None:
+                self._step_flat = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+            if n:
+                ops.reduce_step(self._rows(len(local_models), 0), self._client_weights(local_models),
+                                self._flats["f32"], self._step_flat, n=n)
+            self.step = {e.name: self._step_flat[e.offset:e.offset + e.numel].view(e.shape)
+                         for e in lay.entries if e.cls == STEP}
+
+    # -- aggregate: fedavg_aggregator.py:150-320 -----------------------------------------------------
+    def aggregate(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict]], **kwargs) -> Dict:
+        """Weighted average of the clients' models (then the server-optimizer step); returns the
+        new global model as CPU tensors.  Extra kwargs (client metadata dicts) are ignored."""
+        secure_enabled = cfg_get(self.aggregator_configs, "use_secure_agg", False)
+        assert not (secure_enabled and "_chunk_idx" in kwargs), (
+            "Secure aggregation does not support chunked aggregation yet.")
+        if "_chunk_idx" in kwargs:
+            raise NotImplementedError(
+                "streamed (chunked) aggregation is not implemented on the MI355X path yet")
+        if secure_enabled and all(isinstance(m, dict) and m.get("type") == "masked_update_flat"
+                                  for m in local_models.values()):
+            raise NotImplementedError(
+                "secure-aggregation payloads are not implemented on the MI355X path yet")
+        with self._lock:
+            first = next(iter(local_models.values()))
+            if self._layout is None:
+                self._init_global_state(first)
+            lay = self._layout
+            K = len(local_models)
+            self._stage(local_models)
+            n_step = lay.count[STEP]
+            g = self._flats["f32"]
+            fused = getattr(type(self).compute_steps, "_appfl_amd_native", False)
+            if fused:
+                if n_step:
+                    self._ensure_moments()
+                    ws = None
+                    if K > ops.kchunk():
+                        if self._step_flat is None:
+                            self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+                        ws = self._step_flat
+                    ops.reduce_opt(self._rows(K, 0), self._client_weights(local_models), g,
+                                   self._m, self._v, self._OPT, step_ws=ws, n=n_step, **self._hyper())
+            else:
+                self.compute_steps(local_models)          # user override (may call super())
+                for e in lay.entries:
+                    if e.name in self.step:
+                        ops.apply_step(lay.view(self._flats, e.name).view(-1),
+                                       self.step[e.name].contiguous().view(-1))
+            # entries that bypass the step: plain mean over clients (fedavg_aggregator.py:285-296)
+            if lay.count[MEAN_F32]:
+                ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), g[n_step:], n=lay.count[MEAN_F32])
+            if lay.count[MEAN_I64]:
+                ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
+            if lay.count[MEAN_I32]:
+                ops.mean(self._rows(K, lay.seg_byte[MEAN_I32]), self._flats["i32"], n=lay.count[MEAN_I32])
+            self.step = {}
+            self._staged_for = None
+            out = self._download()
+            self._sync_model(self.model, out)
+            return out
+
+
+class FedAvgMAggregator(FedAvgAggregator):
+    """Server momentum (fedavgm_aggregator.py:9-75).  Needs `server_momentum_param_1`."""
+
+    _OPT = "avgm"
+
+    def _hyper(self):
+        return {"beta1": cfg_require(self.aggregator_configs, "server_momentum_param_1")}
+
+    def _ensure_moments(self):
+        if self._v is None:   # fedavgm_aggregator.py:37-45
+            self._v = torch.zeros(self._layout.count[STEP], dtype=torch.float32, device=self.device)
+
+    @_native
+    def compute_steps(self, local_models):
+        with self._lock:
+            FedAvgAggregator.compute_steps(self, local_models)
+            n = self._layout.count[STEP]
+            if n:
+                self._ensure_moments()
+                ops.server_opt_step(self._step_flat, self._m, self._v, self._OPT, n=n, **self._hyper())
+
+
+class _AdaptiveAggregator(FedAvgMAggregator):
+    """Common part of FedAdam / FedYogi / FedAdagrad: first moment m, second moment v started at
+    tau**2, step = lr*m / (sqrt(v) + tau)."""
+
+    _NEEDS_BETA2 = True
+
+    def _hyper(self):
+        c = self.aggregator_configs
+        return {
+            "lr": cfg_require(c, "server_learning_rate"),
+            "tau": cfg_require(c, "server_adapt_param"),
+            "beta1": cfg_require(c, "server_momentum_param_1"),
+            "beta2": cfg_require(c, "server_momentum_param_2") if self._NEEDS_BETA2 else 0.0,
+        }
+
+    def _ensure_moments(self):
+        if self._m is None:   # fedadam_aggregator.py:41-50: zeros, zeros + tau**2
+            n = self._layout.count[STEP]
+            tau = cfg_require(self.aggregator_configs, "server_adapt_param")
+            self._m = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self._v = torch.empty(n, dtype=torch.float32, device=self.device)
+            ops.fill(self._v, tau ** 2)
+
+
+class FedAdamAggregator(_AdaptiveAggregator):
+    """FedAdam (fedadam_aggregator.py:9-133): `server_learning_rate`, `server_adapt_param`,
+    `server_momentum_param_1`, `server_momentum_param_2`."""
+
+    _OPT = "adam"
+
+
+class FedYogiAggregator(_AdaptiveAggregator):
+    """FedYogi (fedyogi_aggregator.py:9-132); same configuration fields as FedAdam."""
+
+    _OPT = "yogi"
+
+
+class FedAdagradAggregator(_AdaptiveAggregator):
+    """FedAdagrad (fedadagrad_aggregator.py:9-118): `server_learning_rate`,
+    `server_adapt_param`, `server_momentum_param_1`."""
+
+    _OPT = "adagrad"
+    _NEEDS_BETA2 = False

@@ -349,6 +349,25 @@ __global__ __launch_bounds__(kThreads) void flush_mean_kernel(T* g, const T* ste
         g[i] = mean_finish(step[i], kf);
 }
 
+// Server-optimizer epilogue alone: step (in/out), m, v updated in place.
+template <int OPT, int VEC>
+__global__ __launch_bounds__(kThreads) void opt_step_kernel(float* step, float* m, float* v,
+                                                          Hyper h, unsigned n) {
+    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        Pack<VEC> sv = load_state<VEC>(step, i), vv = load_state<VEC>(v, i), mv;
+        if (OPT != FA_OPT_AVGM) mv = load_state<VEC>(m, i);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float mj = (OPT != FA_OPT_AVGM) ? mv.e[j] : 0.0f;
+            sv.e[j] = optimizer_step<OPT>(sv.e[j], mj, vv.e[j], h);
+            if (OPT != FA_OPT_AVGM) mv.e[j] = mj;
+        }
+        store_state<VEC>(step, i, sv);
+        store_state<VEC>(v, i, vv);
+        if (OPT != FA_OPT_AVGM) store_state<VEC>(m, i, mv);
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void fill_kernel(float* p, float value, unsigned n) {
     for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
@@ -741,6 +760,37 @@ int fa_apply_step(float* g, const float* step, size_t n, fa_stream_t stream) {
         else
             hipLaunchKernelGGL((apply_kernel<1>), dim3(grid_for(cnt)), dim3(kThreads), 0, st,
                                g + off, step + off, static_cast<unsigned>(cnt));
+        return launch_status();
+    });
+}
+
+int fa_server_opt_step(float* step, float* m, float* v, size_t n, int opt, double lr,
+                       double beta1, double beta2, double tau, fa_stream_t stream) {
+    if (opt == FA_OPT_NONE) return FA_OK;
+    if (opt < FA_OPT_NONE || opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
+    if (!step || !v || (opt >= FA_OPT_ADAM && !m)) return FA_ERR_INVALID;
+    if (!aligned_to(step, 4) || !aligned_to(v, 4) || (m && !aligned_to(m, 4))) return FA_ERR_ALIGN;
+    const bool a16 = aligned16(step) && aligned16(v) && (!m || aligned16(m));
+    const Hyper h = make_hyper(lr, beta1, beta2, tau);
+    hipStream_t st = as_stream(stream);
+    return for_each_range(n, a16, [&](size_t off, size_t cnt, bool vec) {
+        float* mo = m ? m + off : nullptr;
+        const dim3 grid(grid_for(cnt)), block(kThreads);
+        const unsigned c = static_cast<unsigned>(cnt);
+#define FA_LAUNCH_OPT(OPT)                                                                     \
+    if (vec)                                                                                   \
+        hipLaunchKernelGGL((opt_step_kernel<OPT, 4>), grid, block, 0, st, step + off, mo,      \
+                           v + off, h, c);                                                     \
+    else                                                                                       \
+        hipLaunchKernelGGL((opt_step_kernel<OPT, 1>), grid, block, 0, st, step + off, mo,      \
+                           v + off, h, c);
+        switch (opt) {
+            case FA_OPT_AVGM: FA_LAUNCH_OPT(FA_OPT_AVGM) break;
+            case FA_OPT_ADAM: FA_LAUNCH_OPT(FA_OPT_ADAM) break;
+            case FA_OPT_YOGI: FA_LAUNCH_OPT(FA_OPT_YOGI) break;
+            default: FA_LAUNCH_OPT(FA_OPT_ADAGRAD) break;
+        }
+#undef FA_LAUNCH_OPT
         return launch_status();
     });
 }

@@ -1,0 +1,155 @@
+"""State dict <-> flat device vectors.
+
+The aggregation kernels work on flat vectors, one per arithmetic class:
+
+* ``step``     fp32 entries that take the weighted step (and the server optimizer)
+* ``mean_f32`` fp32 entries that take the plain mean (non-parameters when a model was given)
+* ``mean_i64`` / ``mean_i32`` integer entries (plain mean with truncating division)
+
+(classification: algorithm/aggregator/fedavg_aggregator.py:333-340 of the reference.)
+
+A client's state dict is packed into one ROW of bytes with the segments in that order::
+
+    [ step fp32 ... | mean fp32 ... | pad to 16 | int64 ... | int32 ... | pad to 256 ]
+
+so the fp32 part of every row is one contiguous, 16-byte aligned vector whose first ``n_step``
+elements are the weighted class, and the global state uses the same offsets.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Set, Tuple
+
+import torch
+
+STEP, MEAN_F32, MEAN_I64, MEAN_I32 = "step", "mean_f32", "mean_i64", "mean_i32"
+_ITEMSIZE = {STEP: 4, MEAN_F32: 4, MEAN_I64: 8, MEAN_I32: 4}
+_DTYPE = {STEP: torch.float32, MEAN_F32: torch.float32, MEAN_I64: torch.int64,
+          MEAN_I32: torch.int32}
+ROW_ALIGN = 256
+
+
+def _round_up(x: int, a: int) -> int:
+    return (x + a - 1) // a * a
+
+
+@dataclass(frozen=True)
+class Entry:
+    name: str
+    shape: Tuple[int, ...]
+    dtype: torch.dtype
+    numel: int
+    cls: str
+    offset: int        # element offset inside its class segment
+    byte_offset: int   # byte offset inside a row
+
+
+def classify(dtype: torch.dtype, is_parameter: bool) -> str:
+    """fedavg_aggregator.py:333-340: integers and non-parameters bypass the weighted step."""
+    if dtype == torch.int64:
+        return MEAN_I64
+    if dtype == torch.int32:
+        return MEAN_I32
+    if dtype != torch.float32:
+        raise NotImplementedError(
+            f"state-dict entries of dtype {dtype} are not supported by the MI355X aggregation "
+            "kernels (fp32, int64 and int32 are); there is no CPU fallback")
+    return STEP if is_parameter else MEAN_F32
+
+
+class Layout:
+    """Offsets of every entry of the global state inside the flat vectors and inside a row."""
+
+    def __init__(self, names_shapes_dtypes: Sequence[Tuple[str, Tuple[int, ...], torch.dtype]],
+                 named_parameters: Optional[Set[str]] = None):
+        order = {STEP: [], MEAN_F32: [], MEAN_I64: [], MEAN_I32: []}
+        for name, shape, dtype in names_shapes_dtypes:
+            is_param = named_parameters is None or name in named_parameters
+            order[classify(dtype, is_param)].append((name, tuple(shape), dtype))
+        self.count = {c: sum(_numel(s) for _, s, _ in order[c]) for c in order}
+        self.n_f32 = self.count[STEP] + self.count[MEAN_F32]
+        self.seg_byte = {STEP: 0, MEAN_F32: 4 * self.count[STEP]}
+        self.seg_byte[MEAN_I64] = _round_up(4 * self.n_f32, 16)
+        self.seg_byte[MEAN_I32] = self.seg_byte[MEAN_I64] + 8 * self.count[MEAN_I64]
+        self.row_bytes = _round_up(self.seg_byte[MEAN_I32] + 4 * self.count[MEAN_I32], ROW_ALIGN)
+        by_name: Dict[str, Entry] = {}
+        for c in (STEP, MEAN_F32, MEAN_I64, MEAN_I32):
+            off = 0
+            for name, shape, dtype in order[c]:
+                n = _numel(shape)
+                by_name[name] = Entry(name, shape, dtype, n, c, off,
+                                      self.seg_byte[c] + off * _ITEMSIZE[c])
+                off += n
+        # global-state (dict) order is the order the names were given in
+        self.entries: List[Entry] = [by_name[n] for n, _, _ in names_shapes_dtypes]
+        self.by_name = by_name
+        self.names = [e.name for e in self.entries]
+
+    # -- flat views ---------------------------------------------------------------------------
+    def alloc_state(self, device) -> Dict[str, torch.Tensor]:
+        """Flat global-state vectors: 'f32' (step segment first, then mean_f32), 'i64', 'i32'."""
+        return {
+            "f32": torch.zeros(max(self.n_f32, 1), dtype=torch.float32, device=device),
+            "i64": torch.zeros(max(self.count[MEAN_I64], 1), dtype=torch.int64, device=device),
+            "i32": torch.zeros(max(self.count[MEAN_I32], 1), dtype=torch.int32, device=device),
+        }
+
+    @staticmethod
+    def flat_key(cls: str) -> str:
+        return {STEP: "f32", MEAN_F32: "f32", MEAN_I64: "i64", MEAN_I32: "i32"}[cls]
+
+    def flat_offset(self, e: Entry) -> int:
+        return e.offset + (self.count[STEP] if e.cls == MEAN_F32 else 0)
+
+    def view(self, flats: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
+        e = self.by_name[name]
+        off = self.flat_offset(e)
+        return flats[self.flat_key(e.cls)][off:off + e.numel].view(e.shape)
+
+    def views(self, flats: Dict[str, torch.Tensor], classes: Optional[Iterable[str]] = None
+              ) -> Dict[str, torch.Tensor]:
+        keep = None if classes is None else set(classes)
+        return {e.name: self.view(flats, e.name) for e in self.entries
+                if keep is None or e.cls in keep}
+
+    def matches(self, state: Dict[str, torch.Tensor]) -> bool:
+        """True when `state` has exactly the layout's names, shapes and dtypes."""
+        if len(state) != len(self.entries):
+            return False
+        for e in self.entries:
+            t = state.get(e.name)
+            if t is None or tuple(t.shape) != e.shape or t.dtype != e.dtype:
+                return False
+        return True
+
+
+def _numel(shape: Tuple[int, ...]) -> int:
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+def split_names_by_size(sizes: Dict[str, int], max_chunk_size: int) -> List[List[str]]:
+    """Chunking rule of misc/memory_utils.py:317-379 on (name -> bytes): names sorted, greedy
+    fill up to max_chunk_size, an oversized tensor gets a chunk of its own."""
+    chunks: List[List[str]] = []
+    cur: List[str] = []
+    cur_size = 0
+    for key in sorted(sizes):
+        sz = sizes[key]
+        if sz > max_chunk_size:
+            if cur:
+                chunks.append(cur)
+                cur, cur_size = [], 0
+            chunks.append([key])
+            continue
+        if cur_size + sz > max_chunk_size and cur:
+            chunks.append(cur)
+            cur, cur_size = [], 0
+        cur.append(key)
+        cur_size += sz
+    if cur:
+        chunks.append(cur)
+    return chunks

@@ -39,9 +39,14 @@ def _dev(t: Optional[torch.Tensor], dtype=None) -> Optional[int]:
     return t.data_ptr()
 
 
-def _check_rows(x: Sequence[torch.Tensor], n: int, dtype) -> "C.Array":
+def _check_rows(x: Sequence, n: int, dtype) -> "C.Array":
+    """Client buffers as device tensors, or as raw device addresses (ints) the caller vouches
+    for (rows of a staging slab)."""
     ptrs = []
     for t in x:
+        if isinstance(t, int):
+            ptrs.append(t)
+            continue
         if t.numel() < n:
             raise ValueError(f"client buffer has {t.numel()} elements, need {n}")
         ptrs.append(_dev(t, dtype))
@@ -101,6 +106,19 @@ def reduce_step(x, w, g, step_out, n: Optional[int] = None) -> None:
                                  _dev(g, torch.float32), _dev(step_out, torch.float32), n,
                                  _stream(g))
     N.check(rc, "fa_reduce_step")
+
+
+def server_opt_step(step, m, v, opt: str, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
+                    n: Optional[int] = None) -> None:
+    """Optimizer epilogue alone on an already averaged step (fa_server_opt_step)."""
+    n = step.numel() if n is None else n
+    for t in (m, v):
+        if t is not None and t.numel() < n:
+            raise ValueError("moment tensor shorter than n")
+    rc = N.load().fa_server_opt_step(_dev(step, torch.float32), _dev(m, torch.float32),
+                                     _dev(v, torch.float32), n, OPT_CODES[opt], float(lr),
+                                     float(beta1), float(beta2), float(tau), _stream(step))
+    N.check(rc, "fa_server_opt_step")
 
 
 def apply_step(g, step, n: Optional[int] = None) -> None:

@@ -1,0 +1,128 @@
+"""Host -> device staging of client state dicts.
+
+Each arriving client's tensors are packed (native multi-threaded memcpy, fa_pack_host) into a
+pinned host slot laid out as one row of the :class:`~appfl_amd.layout.Layout`, and the slot is
+copied to row k of a device slab on a dedicated copy stream, so the packing of client k+1
+overlaps the PCIe transfer of client k.  Stands where the reference materialises per-tensor CPU
+tensors and hands them to the aggregator (agent/server.py:505-525, sync_scheduler.py:46).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _native as N
+from .layout import Layout
+
+PACK_THREADS = 8
+
+
+class ClientSlab:
+    def __init__(self, layout: Layout, device: torch.device, slots: int = 3):
+        self.layout = layout
+        self.device = device
+        self.row_bytes = layout.row_bytes
+        self.capacity = 0
+        self.slab: Optional[torch.Tensor] = None
+        self.nslots = slots
+        self.pinned = torch.empty((slots, self.row_bytes), dtype=torch.uint8, pin_memory=True)
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.slot_free = [None] * slots   # event recorded after the slot's last H2D copy
+        self.next_slot = 0
+        self.last_copy: Optional[torch.cuda.Event] = None
+
+    def reserve(self, rows: int) -> None:
+        if rows <= self.capacity:
+            return
+        need = rows * self.row_bytes
+        free, _ = torch.cuda.mem_get_info(self.device)
+        have = 0 if self.slab is None else self.slab.numel()
+        if need - have > free:
+            raise MemoryError(
+                f"staging {rows} client updates needs {need / 2**30:.1f} GiB of device memory, "
+                f"{free / 2**30:.1f} GiB free")
+        # kernels of earlier rounds may still read the old slab on the compute stream
+        torch.cuda.current_stream(self.device).synchronize()
+        self.copy_stream.synchronize()
+        self.slab = None
+        self.slab = torch.empty((rows, self.row_bytes), dtype=torch.uint8, device=self.device)
+        self.capacity = rows
+
+    def row_ptr(self, k: int) -> int:
+        return self.slab.data_ptr() + k * self.row_bytes
+
+    def row_view(self, k: int, byte_offset: int, numel: int, dtype: torch.dtype) -> torch.Tensor:
+        item = torch.empty((), dtype=dtype).element_size()
+        return self.slab[k, byte_offset:byte_offset + numel * item].view(dtype)
+
+    def begin_round(self) -> None:
+        """Order this round's uploads after the kernels that read the slab last round."""
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def upload(self, k: int, state: Dict[str, torch.Tensor], fill_missing_from=None) -> None:
+        """Pack `state` into row k.  Entries of the layout that `state` lacks and that take the
+        weighted step are filled from `fill_missing_from` (the global fp32 vector), which makes
+        their difference zero -- the reference skips such a client for that entry
+        (fedavg_aggregator.py:360-361); a missing plain-mean entry raises KeyError (:289)."""
+        lay = self.layout
+        host_src: List[int] = []
+        host_off: List[int] = []
+        host_len: List[int] = []
+        keep = []          # converted tensors must outlive the memcpy
+        dev_items = []
+        missing = []
+        for e in lay.entries:
+            t = state.get(e.name)
+            if t is None:
+                if e.cls != "step":
+                    raise KeyError(e.name)
+                missing.append(e)
+                continue
+            if t.numel() != e.numel:
+                raise ValueError(f"{e.name}: client tensor has {t.numel()} elements, "
+                                 f"global state has {e.numel}")
+            if t.dtype != e.dtype:
+                t = t.to(e.dtype)
+            if not t.is_contiguous():
+                t = t.contiguous()
+            if t.is_cuda:
+                dev_items.append((e, t))
+                continue
+            keep.append(t)
+            if e.numel:
+                host_src.append(t.data_ptr())
+                host_off.append(e.byte_offset)
+                host_len.append(e.numel * t.element_size())
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % self.nslots
+        if self.slot_free[slot] is not None:
+            self.slot_free[slot].synchronize()
+        T = len(host_src)
+        if T:
+            rc = N.load().fa_pack_host(
+                C.c_void_p(self.pinned[slot].data_ptr()),
+                (C.c_void_p * T)(*host_src), (C.c_size_t * T)(*host_off),
+                (C.c_size_t * T)(*host_len), T, PACK_THREADS)
+            N.check(rc, "fa_pack_host")
+        with torch.cuda.stream(self.copy_stream):
+            if T:
+                self.slab[k].copy_(self.pinned[slot], non_blocking=True)
+            for e, t in dev_items:
+                self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(t.view(-1), non_blocking=True)
+            for e in missing:
+                off = lay.flat_offset(e)
+                self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(
+                    fill_missing_from[off:off + e.numel], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.slot_free[slot] = ev
+        self.last_copy = ev
+        del keep
+
+    def end_round(self) -> None:
+        """Make the compute stream wait for every upload of this round."""
+        if self.last_copy is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.last_copy)

@@ -106,6 +106,16 @@ int fa_reduce_opt_slab(const float* slab, size_t stride, const double* w, int K,
 int fa_reduce_step(const float* const* x, const double* w, int K, const float* g,
                    float* step_out, size_t n, fa_stream_t stream);
 
+/*
+ * Server-optimizer epilogue alone, for callers that computed the averaged step themselves:
+ * step (in: averaged pseudo-gradient, out: optimizer step), m, v updated in place with the
+ * formulas of fa_reduce_opt.  Replaces the part of the subclass compute_steps bodies after
+ * super().compute_steps() (fedavgm_aggregator.py:48-61, fedadam_aggregator.py:60-99,
+ * fedyogi_aggregator.py:60-97, fedadagrad_aggregator.py:59-91).  opt = FA_OPT_NONE is a no-op.
+ */
+int fa_server_opt_step(float* step, float* m, float* v, size_t n, int opt, double lr,
+                       double beta1, double beta2, double tau, fa_stream_t stream);
+
 /* g[i] = g[i] + step[i]  (fedavg_aggregator.py:281-283; fedbuff_aggregator.py:88). */
 int fa_apply_step(float* g, const float* step, size_t n, fa_stream_t stream);
 

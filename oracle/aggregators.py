@@ -1,0 +1,384 @@
+"""CPU restatement of APPFL's FedAvg-family and FedAsync/FedBuff aggregators on state dicts.
+
+TEST INFRASTRUCTURE ONLY: the checker for ``appfl_amd.aggregator`` (tests/, the smoke run and
+the benchmark's cpu_baseline leg).  Never imported by the product package.
+
+Written in numpy float32 arithmetic, one numpy operation per PyTorch tensor operation of the
+reference, so every intermediate is rounded where the reference rounds it.  Pinned bit-for-bit
+against golden vectors produced by the reference's own classes (tests/golden/); the reference's
+test-suite holds no numeric vectors for this path.
+
+Reference files followed (relative to src/appfl/):
+  algorithm/aggregator/base_aggregator.py:5-26
+  algorithm/aggregator/fedavg_aggregator.py:28-404
+  algorithm/aggregator/fedavgm_aggregator.py:19-75
+  algorithm/aggregator/fedadam_aggregator.py:22-133
+  algorithm/aggregator/fedyogi_aggregator.py:22-132
+  algorithm/aggregator/fedadagrad_aggregator.py:21-118
+  algorithm/aggregator/fedasync_aggregator.py:20-277
+  algorithm/aggregator/fedbuff_aggregator.py:15-158
+  misc/memory_utils.py:15-36, 75-131
+
+State dicts come in as ``{name: torch.Tensor | np.ndarray}`` and go out as
+``{name: np.ndarray}`` (same dtypes and shapes).
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+F32 = np.float32
+_INT = (np.dtype(np.int64), np.dtype(np.int32))
+
+
+def to_np(t) -> np.ndarray:
+    if isinstance(t, np.ndarray):
+        return t
+    return t.detach().cpu().numpy()
+
+
+def cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def _f32(x: float) -> np.float32:
+    """A Python float that multiplies / adds to an fp32 tensor is rounded to fp32 once."""
+    return np.float32(x)
+
+
+def _int_div(s: np.ndarray, k: int) -> np.ndarray:
+    """torch.div(int_tensor, k).type(int): float32 true division, truncation
+    (memory_utils.py:109-110)."""
+    return np.trunc(s.astype(F32) / F32(k)).astype(s.dtype)
+
+
+class OracleBase:
+    """base_aggregator.py:5-10."""
+
+    def set_client_sample_size(self, client_id, sample_size):
+        if not hasattr(self, "client_sample_size"):
+            self.client_sample_size = {}
+        self.client_sample_size[client_id] = sample_size
+
+
+def _model_info(model):
+    if model is None:
+        return None, None
+    state = {k: to_np(v).copy() for k, v in model.state_dict().items()}
+    named = {n for n, _ in model.named_parameters()}
+    return state, named
+
+
+class OracleFedAvg(OracleBase):
+    """fedavg_aggregator.py:17-404 (un-chunked, no secure aggregation)."""
+
+    def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
+        self.model = model
+        self.cfg = aggregator_configs or {}
+        self.client_weights_mode = cfg_get(self.cfg, "client_weights_mode", "equal")
+        self.model_state, self.named_parameters = _model_info(model)
+        self.global_state: Optional[Dict[str, np.ndarray]] = None
+        self.step: Dict[str, np.ndarray] = {}
+
+    # fedavg_aggregator.py:136-148
+    def get_parameters(self, **kwargs):
+        if self.global_state is None:
+            if self.model_state is None:
+                raise ValueError("Model is not provided to the aggregator.")
+            return {k: v.copy() for k, v in self.model_state.items()}
+        return {k: v.copy() for k, v in self.global_state.items()}
+
+    def _is_step_name(self, name) -> bool:
+        # fedavg_aggregator.py:333-340
+        if self.named_parameters is not None and name not in self.named_parameters:
+            return False
+        return self.global_state[name].dtype not in _INT
+
+    def _weights(self, local_models):
+        # fedavg_aggregator.py:343-358
+        sizes = getattr(self, "client_sample_size", {})
+        total = sum(sizes[c] for c in local_models if c in sizes)
+        out = {}
+        for cid in local_models:
+            if self.client_weights_mode == "sample_size" and cid in sizes and total > 0:
+                out[cid] = sizes[cid] / total
+            else:
+                out[cid] = 1.0 / len(local_models)
+        return out
+
+    def compute_steps(self, local_models):
+        # fedavg_aggregator.py:322-368
+        for name in self.global_state:
+            if self._is_step_name(name):
+                self.step[name] = np.zeros_like(self.global_state[name])
+        w = self._weights(local_models)
+        for cid, model in local_models.items():
+            wk = _f32(w[cid])
+            for name in model:
+                if name in self.step:
+                    diff = to_np(model[name]).astype(F32, copy=False) - self.global_state[name]
+                    self.step[name] = self.step[name] + diff * wk
+
+    def aggregate(self, local_models, **kwargs):
+        local_models = {c: {k: to_np(v) for k, v in m.items()} for c, m in local_models.items()}
+        first = next(iter(local_models.values()))
+        if self.global_state is None:
+            # fedavg_aggregator.py:228-271
+            if self.model_state is not None:
+                self.global_state = {n: self.model_state[n].copy() for n in first
+                                     if n in self.model_state}
+            else:
+                self.global_state = {n: t.copy() for n, t in first.items()}
+        self.compute_steps(local_models)
+        # fedavg_aggregator.py:276-299
+        for name in self.global_state:
+            if name in self.step:
+                self.global_state[name] = self.global_state[name] + self.step[name]
+            else:
+                g = self.global_state[name]
+                s = np.zeros_like(g)
+                for model in local_models.values():
+                    s = s + model[name].astype(g.dtype, copy=False)
+                self.global_state[name] = _int_div(s, len(local_models)) if g.dtype in _INT \
+                    else (s / g.dtype.type(len(local_models))).astype(g.dtype)
+        self.last_step = dict(self.step)
+        self.step = {}
+        if self.model_state is not None:
+            for k, v in self.global_state.items():   # load_state_dict(strict=False)
+                if k in self.model_state:
+                    self.model_state[k] = v.copy()
+        return {k: v.copy() for k, v in self.global_state.items()}
+
+
+class OracleFedAvgM(OracleFedAvg):
+    """fedavgm_aggregator.py:28-61."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.v_vector: Dict[str, np.ndarray] = {}
+
+    def compute_steps(self, local_models):
+        super().compute_steps(local_models)
+        if len(self.v_vector) == 0:
+            for name in self.step:
+                self.v_vector[name] = np.zeros_like(self.step[name])
+        b1 = _f32(cfg_get(self.cfg, "server_momentum_param_1"))
+        for name in self.step:
+            self.v_vector[name] = self.v_vector[name] * b1 + self.step[name]
+            self.step[name] = self.v_vector[name].copy()
+
+
+class _OracleAdaptive(OracleFedAvg):
+    """Shared shape of fedadam / fedyogi / fedadagrad compute_steps."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.m_vector: Dict[str, np.ndarray] = {}
+        self.v_vector: Dict[str, np.ndarray] = {}
+
+    def _second_moment(self, v, s2, omb2, b2):
+        raise NotImplementedError
+
+    def compute_steps(self, local_models):
+        super().compute_steps(local_models)
+        tau = cfg_get(self.cfg, "server_adapt_param")
+        if len(self.m_vector) == 0:
+            # fedadam_aggregator.py:41-50: zeros + tau**2 (Python double, rounded to fp32)
+            for name in self.step:
+                self.m_vector[name] = np.zeros_like(self.step[name])
+                self.v_vector[name] = np.zeros_like(self.step[name]) + _f32(tau ** 2)
+        beta1 = cfg_get(self.cfg, "server_momentum_param_1")
+        beta2 = cfg_get(self.cfg, "server_momentum_param_2", 0.0)
+        b1, omb1 = _f32(beta1), _f32(1 - beta1)
+        b2, omb2 = _f32(beta2), _f32(1 - beta2)
+        lr = _f32(cfg_get(self.cfg, "server_learning_rate"))
+        for name in self.step:
+            st = self.step[name]
+            with np.errstate(all="ignore"):      # inf / nan propagate as in the reference
+                # fedadam_aggregator.py:64-73
+                self.m_vector[name] = self.m_vector[name] * b1 + st * omb1
+                s2 = st * st
+                self.v_vector[name] = self._second_moment(self.v_vector[name], s2, omb2, b2)
+                # fedadam_aggregator.py:89-99.  np.sqrt is the IEEE correctly rounded sqrt; the
+                # reference's torch.sqrt (MKL vector math) may be one ulp lower.
+                num = lr * self.m_vector[name]
+                den = np.sqrt(self.v_vector[name]) + _f32(tau)
+                self.step[name] = num / den
+
+
+class OracleFedAdam(_OracleAdaptive):
+    def _second_moment(self, v, s2, omb2, b2):
+        return v * b2 + s2 * omb2            # fedadam_aggregator.py:76-86
+
+
+class OracleFedYogi(_OracleAdaptive):
+    def _second_moment(self, v, s2, omb2, b2):
+        sg = np.sign(v - s2)                 # fedyogi_aggregator.py:76-84
+        return v - (s2 * sg) * omb2
+
+
+class OracleFedAdagrad(_OracleAdaptive):
+    def _second_moment(self, v, s2, omb2, b2):
+        return v + s2                        # fedadagrad_aggregator.py:75-78
+
+
+def staleness_fn_factory(name, **kwargs):
+    """fedasync_aggregator.py:266-277."""
+    if name == "constant":
+        return lambda u: 1
+    if name == "polynomial":
+        a = kwargs["a"]
+        return lambda u: (u + 1) ** (-a)
+    if name == "hinge":
+        a, b = kwargs["a"], kwargs["b"]
+        return lambda u: 1 if u <= b else 1.0 / (a * (u - b) + 1.0)
+    raise NotImplementedError
+
+
+class OracleFedAsync(OracleBase):
+    """fedasync_aggregator.py:14-277."""
+
+    def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
+        self.model = model
+        self.cfg = aggregator_configs or {}
+        self.client_weights_mode = cfg_get(self.cfg, "client_weights_mode", "equal")
+        self.optimize_memory = cfg_get(self.cfg, "optimize_memory", True)
+        self.model_state, self.named_parameters = _model_info(model)
+        self.global_state = None
+        self.staleness_fn = staleness_fn_factory(
+            cfg_get(self.cfg, "staleness_fn", "constant"),
+            **dict(cfg_get(self.cfg, "staleness_fn_kwargs", {}) or {}))
+        self.alpha = cfg_get(self.cfg, "alpha", 0.9)
+        self.global_step = 0
+        self.client_step = {}
+        self.step = {}
+
+    def get_parameters(self, client_id=None, **kwargs):
+        if client_id is not None:
+            self.client_step[client_id] = self.global_step   # :82-83
+        if self.global_state is None:
+            if self.model_state is None:
+                raise ValueError("Model is not provided to the aggregator.")
+            return {k: v.copy() for k, v in self.model_state.items()}
+        return {k: v.copy() for k, v in self.global_state.items()}
+
+    def _init_global(self, local_model):
+        # :110-149 -- model entries when every client key is in the model, else the client's
+        if self.model_state is not None and all(n in self.model_state for n in local_model):
+            self.global_state = {n: self.model_state[n].copy() for n in local_model}
+        else:
+            self.global_state = {n: t.copy() for n, t in local_model.items()}
+
+    def _is_step_name(self, name) -> bool:
+        if self.named_parameters is not None and name not in self.named_parameters:
+            return False
+        return self.global_state[name].dtype not in _INT
+
+    def _alpha_t(self, client_id) -> float:
+        # :207-229
+        if client_id not in self.client_step:
+            self.client_step[client_id] = 0
+        sizes = getattr(self, "client_sample_size", {})
+        if self.client_weights_mode == "sample_size" and client_id in sizes:
+            weight = sizes[client_id] / sum(sizes.values())
+        else:
+            weight = 1.0 / cfg_get(self.cfg, "num_clients", 1)
+        return self.alpha * self.staleness_fn(self.global_step - self.client_step[client_id]) * weight
+
+    def _arrival_step(self, x, g, alpha_t, gradient_based, sub_form):
+        a = _f32(alpha_t)
+        if not gradient_based:
+            return a * (x - g)                 # :253-258 / :263
+        if sub_form:
+            return F32(0.0) - a * x            # :246-251  zeros.sub_(x, alpha=a)
+        return a * (-x)                        # :261
+
+    def compute_steps(self, client_id, local_model):
+        alpha_t = self._alpha_t(client_id)
+        gb = cfg_get(self.cfg, "gradient_based", False)
+        for name in self.global_state:
+            if not self._is_step_name(name):
+                continue
+            self.step[name] = self._arrival_step(local_model[name], self.global_state[name],
+                                                 alpha_t, gb, bool(self.optimize_memory))
+
+    def aggregate(self, client_id, local_model, **kwargs):
+        local_model = {k: to_np(v) for k, v in local_model.items()}
+        if self.global_state is None:
+            self._init_global(local_model)
+        self.compute_steps(client_id, local_model)
+        for name in self.global_state:          # :156-168
+            if name in self.step:
+                self.global_state[name] = self.global_state[name] + self.step[name]
+            else:
+                self.global_state[name] = local_model[name].copy()
+        self._sync_model()
+        self.global_step += 1                   # :173-174
+        self.client_step[client_id] = self.global_step
+        return {k: v.copy() for k, v in self.global_state.items()}
+
+    def _sync_model(self):
+        if self.model_state is not None:
+            for k, v in self.global_state.items():
+                if k in self.model_state:
+                    self.model_state[k] = v.copy()
+
+
+class OracleFedBuff(OracleFedAsync):
+    """fedbuff_aggregator.py:9-158."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.buff_size = 0
+        self.K = cfg_get(self.cfg, "K")
+
+    def compute_steps(self, client_id, local_model):
+        if self.buff_size == 0:                 # :116-124
+            for name in self.global_state:
+                self.step[name] = np.zeros_like(self.global_state[name])
+        alpha_t = self._alpha_t(client_id)
+        gb = cfg_get(self.cfg, "gradient_based", False)
+        for name in self.global_state:          # :145-158
+            if not self._is_step_name(name):
+                self.step[name] = self.step[name] + local_model[name].astype(
+                    self.step[name].dtype, copy=False)
+            else:
+                self.step[name] = self.step[name] + self._arrival_step(
+                    local_model[name], self.global_state[name], alpha_t, gb, False)
+
+    def aggregate(self, client_id, local_model, **kwargs):
+        local_model = {k: to_np(v) for k, v in local_model.items()}
+        if self.global_state is None:
+            self._init_global(local_model)
+        self.compute_steps(client_id, local_model)
+        self.buff_size += 1
+        if self.buff_size == self.K:            # :75-94
+            for name in self.global_state:
+                g = self.global_state[name]
+                if not self._is_step_name(name):
+                    self.global_state[name] = _int_div(self.step[name], self.K) \
+                        if g.dtype in _INT else (self.step[name] / g.dtype.type(self.K)).astype(g.dtype)
+                else:
+                    self.global_state[name] = g + self.step[name]
+            self.global_step += 1
+            self.buff_size = 0
+            self._sync_model()
+        self.client_step[client_id] = self.global_step   # :100
+        return {k: v.copy() for k, v in self.global_state.items()}
+
+
+ORACLES = {
+    "FedAvgAggregator": OracleFedAvg,
+    "FedAvgMAggregator": OracleFedAvgM,
+    "FedAdamAggregator": OracleFedAdam,
+    "FedYogiAggregator": OracleFedYogi,
+    "FedAdagradAggregator": OracleFedAdagrad,
+    "FedAsyncAggregator": OracleFedAsync,
+    "FedBuffAggregator": OracleFedBuff,
+}

@@ -74,6 +74,13 @@ def reduce_step(x, w, g, step_out) -> None:
     assert rc == 0, rc
 
 
+def server_opt_step(step, m, v, opt, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0) -> None:
+    rc = load().or_server_opt_step(_ptr(_chk(step, np.float32)), _ptr(m), _ptr(v),
+                                   C.c_size_t(step.size), C.c_int(opt), C.c_double(lr),
+                                   C.c_double(beta1), C.c_double(beta2), C.c_double(tau))
+    assert rc == 0, rc
+
+
 def apply_step(g, step) -> None:
     load().or_apply_step(_ptr(_chk(g, np.float32)), _ptr(_chk(step, np.float32)),
                          C.c_size_t(g.size))

@@ -93,6 +93,44 @@ int or_reduce_opt(const float* const* x, const double* w, int K, float* g, float
     return 0;
 }
 
+/* Optimizer epilogue alone on an averaged step (same formulas as or_reduce_opt). */
+int or_server_opt_step(float* step, float* m, float* v, size_t n, int opt, double lr, double beta1,
+                       double beta2, double tau) {
+    if (opt == OPT_NONE) return 0;
+    if (opt < OPT_NONE || opt > OPT_ADAGRAD) return -1;
+    const float lr_f = (float)lr, b1 = (float)beta1, omb1 = (float)(1.0 - beta1);
+    const float b2 = (float)beta2, omb2 = (float)(1.0 - beta2), tau_f = (float)tau;
+    for (size_t i = 0; i < n; ++i) {
+        float st = step[i];
+        if (opt == OPT_AVGM) {
+            float mt = v[i] * b1;
+            v[i] = mt + st;
+            step[i] = v[i];
+            continue;
+        }
+        float mt = m[i] * b1;
+        float sm = st * omb1;
+        m[i] = mt + sm;
+        float s2 = st * st;
+        if (opt == OPT_ADAM) {
+            float vt = v[i] * b2;
+            float sq = s2 * omb2;
+            v[i] = vt + sq;
+        } else if (opt == OPT_YOGI) {
+            float sg = sign_f32(v[i] - s2);
+            float yu = s2 * sg;
+            float ys = yu * omb2;
+            v[i] = v[i] - ys;
+        } else {
+            v[i] = v[i] + s2;
+        }
+        float num = lr_f * m[i];
+        float den = sqrtf(v[i]) + tau_f;
+        step[i] = num / den;
+    }
+    return 0;
+}
+
 /* Step only: fedavg_aggregator.py:322-368. */
 int or_reduce_step(const float* const* x, const double* w, int K, const float* g, float* step_out,
                    size_t n) {

@@ -1,0 +1,102 @@
+"""Loading and checking tests/golden/golden.npz (vectors produced by the reference's classes)."""
+
+import hashlib
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.npz")
+_cache = {}
+
+
+def load():
+    if "z" not in _cache:
+        z = np.load(GOLDEN, allow_pickle=False)
+        _cache["z"] = z
+        _cache["index"] = json.loads(bytes(z["__index__"]).decode())
+    return _cache["z"], _cache["index"]
+
+
+def record_hash(d) -> str:
+    h = hashlib.sha256()
+    for k in sorted(d):
+        a = np.ascontiguousarray(d[k])
+        h.update(k.encode())
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def canonical_nan(a):
+    """Same array with every NaN replaced by one quiet NaN: x86 and gfx950 produce NaNs of
+    different sign / payload for the same invalid operation (inf - inf), so bit comparisons
+    between host and device treat all NaNs as equal."""
+    a = np.ascontiguousarray(a)
+    if a.dtype.kind == "f" and np.isnan(a).any():
+        a = a.copy()
+        a[np.isnan(a)] = np.float32("nan")
+    return a
+
+
+def same_bits(a, b) -> bool:
+    a, b = canonical_nan(a), canonical_nan(b)
+    return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(_bits(a), _bits(b))
+
+
+def _close(got, want, rtol):
+    """|got - want| <= rtol * max|finite want| elementwise; inf / nan patterns must coincide."""
+    got, want = np.asarray(got), np.asarray(want)
+    if want.dtype.kind != "f":
+        return np.array_equal(got, want), 0.0
+    fin = np.isfinite(want)
+    if not np.array_equal(fin, np.isfinite(got)):
+        return False, float("inf")
+    if not np.array_equal(got[~fin], want[~fin], equal_nan=True):
+        return False, float("inf")
+    if not fin.any():
+        return True, 0.0
+    scale = float(np.max(np.abs(want[fin]))) or 1.0
+    err = float(np.max(np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64)))) / scale
+    return err <= rtol, err
+
+
+def check_records(sc_id, rec, rtol=None):
+    """Comparison of a scenario's records with the golden file: bit-exact when rtol is None,
+    else every stored tensor within rtol of the tensor's largest magnitude."""
+    z, index = load()
+    want = index[sc_id]
+    assert [r["label"] for r in want] == [lbl for lbl, _ in rec], \
+        f"{sc_id}: record labels differ: {[lbl for lbl, _ in rec]} vs {[r['label'] for r in want]}"
+    worst = 0.0
+    for i, ((label, d), w) in enumerate(zip(rec, want)):
+        assert sorted(d) == w["names"], f"{sc_id}/{label}: keys {sorted(d)} vs {w['names']}"
+        if record_hash(d) == w["sha256"]:
+            continue
+        for k in sorted(d):
+            key, sub = f"{sc_id}|{i}|{k}", False
+            if key not in z.files and key + "|s97" in z.files:
+                key, sub = key + "|s97", True
+            if key not in z.files:
+                continue
+            g = z[key]
+            mine = d[k].ravel()[::97] if sub else d[k]
+            assert mine.dtype == g.dtype and mine.shape == g.shape, \
+                f"{sc_id}/{label}/{k}: {mine.dtype}{mine.shape} vs {g.dtype}{g.shape}"
+            if rtol is None:
+                bad = np.nonzero(_bits(mine).ravel() != _bits(g).ravel())[0]
+                assert bad.size == 0, (
+                    f"{sc_id}/{label}/{k}: {bad.size} of {g.size} elements differ; first {bad[:4]}: "
+                    f"got {mine.ravel()[bad[:4]]} want {g.ravel()[bad[:4]]}")
+            else:
+                ok, err = _close(mine, g, rtol)
+                worst = max(worst, err)
+                assert ok, f"{sc_id}/{label}/{k}: relative error {err:.3g} > {rtol}"
+        assert rtol is not None, f"{sc_id}/{label}: hash differs (in a tensor stored by hash only)"
+    return worst

@@ -1,0 +1,255 @@
+"""Scripted aggregation scenarios shared by the golden-vector generator, the oracle tests and the
+GPU parity tests.  One scenario = one aggregator instance driven through a fixed sequence of
+calls on inputs from the counter-based PRNG, so the reference (tests/golden/gen_golden.py), the
+CPU oracle and the HIP aggregators all see identical bits.
+
+`run_scenario(factory, sc)` returns an ordered list of (label, {name: np.ndarray}) records.
+`factory(class_name, model, cfg_dict)` builds the aggregator under test.
+"""
+
+from __future__ import annotations
+
+import itertools
+from typing import Callable, Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from oracle import synth
+
+# name -> (shape, dtype)
+TOY = {
+    "conv.weight": ((4, 3, 3, 3), "f32"),
+    "bn.weight": ((4,), "f32"),
+    "bn.bias": ((4,), "f32"),
+    "bn.running_mean": ((4,), "f32"),
+    "bn.running_var": ((4,), "f32"),
+    "bn.num_batches_tracked": ((), "i64"),
+    "fc.weight": ((10, 64), "f32"),
+    "fc.bias": ((10,), "f32"),
+}
+# odd sizes (tails, unaligned entry offsets), an int32 entry and a multi-element int64 entry
+RAGGED = {
+    "a": ((5,), "f32"),
+    "steps": ((3,), "i64"),
+    "b": ((7, 3), "f32"),
+    "cnt32": ((5,), "i32"),
+    "c": ((1,), "f32"),
+    "w": ((100003,), "f32"),
+}
+BIG = {"w": ((1000003,), "f32"), "n": ((), "i64")}
+SPECS = {"toy": TOY, "ragged": RAGGED, "big": BIG}
+
+_NP = {"f32": np.float32, "i64": np.int64, "i32": np.int32}
+
+
+class ToyModel(torch.nn.Module):
+    """conv -> bn -> fc with the TOY entry names; parameters come from the PRNG, not torch's."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(3, 4, 3, bias=False)
+        self.bn = torch.nn.BatchNorm2d(4)
+        self.fc = torch.nn.Linear(64, 10)
+        with torch.no_grad():
+            for i, (name, t) in enumerate(self.state_dict().items()):
+                if t.dtype == torch.int64:
+                    t.fill_(3)
+                else:
+                    t.copy_(torch.from_numpy(
+                        synth.fill(t.numel(), 500 + i, scale=0.05).reshape(tuple(t.shape))))
+            self.bn.running_var.abs_().add_(1.0)
+
+
+def _name_seed(name: str) -> int:
+    return sum((i + 1) * ord(c) for i, c in enumerate(name)) % 100000
+
+
+def make_state(spec: Dict, seed: int, base_seed: int = 7, scale: float = 0.02,
+               gradient: bool = False) -> Dict[str, torch.Tensor]:
+    """One client's state dict: common base (seed 7) + small client-specific noise."""
+    out = {}
+    for name, (shape, kind) in spec.items():
+        n = int(np.prod(shape)) if shape else 1
+        ns = _name_seed(name)
+        if kind == "f32":
+            if gradient:
+                a = synth.fill(n, seed * 131 + ns, scale=scale)
+            else:
+                base = synth.fill(n, base_seed * 131 + ns, scale=0.05)
+                a = synth.fill(n, seed * 131 + ns, scale=scale, base=base)
+            if n >= 8:
+                # edge values: exact base (zero difference), a signed zero, a huge value, a denormal
+                a[1] = 0.0 if gradient else synth.fill(n, base_seed * 131 + ns, scale=0.05)[1]
+                a[2] = -0.0
+                if seed % 3 == 0:
+                    a[3] = 3.0e30
+                a[4] = 1e-41
+        else:
+            a = synth.ints(seed * 131 + ns, n, -9, 10, _NP[kind])
+        out[name] = torch.from_numpy(a.reshape(shape))
+    return out
+
+
+def _snap(d) -> Dict[str, np.ndarray]:
+    out = {}
+    for k, v in d.items():
+        a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        out[k] = np.array(a, copy=True)
+    return out
+
+
+HP = {
+    "FedAvgAggregator": {},
+    "FedAvgMAggregator": {"server_momentum_param_1": 0.9},
+    "FedAdamAggregator": {"server_learning_rate": 0.1, "server_adapt_param": 1e-3,
+                          "server_momentum_param_1": 0.9, "server_momentum_param_2": 0.99},
+    "FedYogiAggregator": {"server_learning_rate": 0.01, "server_adapt_param": 1e-3,
+                          "server_momentum_param_1": 0.9, "server_momentum_param_2": 0.99},
+    "FedAdagradAggregator": {"server_learning_rate": 0.1, "server_adapt_param": 1e-3,
+                             "server_momentum_param_1": 0.9},
+}
+SYNC_CLASSES = list(HP)
+
+
+def sync_scenarios() -> List[Dict]:
+    out = []
+    for cls, with_model, mode, optmem in itertools.product(
+            SYNC_CLASSES, (False, True), ("equal", "sample_size"), (True, False)):
+        cfg = dict(HP[cls], client_weights_mode=mode, optimize_memory=optmem)
+        out.append({
+            "id": f"{cls[:-10]}-{'model' if with_model else 'nomodel'}-{mode}-"
+                  f"{'opt' if optmem else 'orig'}",
+            "kind": "sync", "cls": cls, "spec": "toy", "model": with_model, "cfg": cfg,
+            # K per round; client ids rotate so that sample sizes and membership change
+            "rounds": [2, 4, 7],
+            "sample_sizes": {c: 3 + 8 * c + (c % 3) for c in range(6)} if mode == "sample_size" else {},
+        })
+    for cls in SYNC_CLASSES:
+        out.append({"id": f"{cls[:-10]}-ragged", "kind": "sync", "cls": cls, "spec": "ragged",
+                    "model": False, "cfg": dict(HP[cls], client_weights_mode="sample_size"),
+                    "rounds": [3, 5, 1], "sample_sizes": {c: 10 + 7 * c for c in range(5)}})
+    for cls in ("FedAvgAggregator", "FedAvgMAggregator"):
+        out.append({"id": f"{cls[:-10]}-big", "kind": "sync", "cls": cls, "spec": "big",
+                    "model": False, "cfg": dict(HP[cls], client_weights_mode="equal"),
+                    "rounds": [3, 2], "sample_sizes": {}, "hash_only": True})
+    # Yogi sign(0): tau = 2^-10 so v0 = 2^-20; two clients at g + 2^-10 give step = 2^-10 exactly
+    out.append({"id": "FedYogi-sign0", "kind": "sync", "cls": "FedYogiAggregator", "spec": "toy",
+                "model": False, "cfg": dict(HP["FedYogiAggregator"], server_adapt_param=2.0 ** -10,
+                                            client_weights_mode="equal"),
+                "rounds": [2, 2], "sample_sizes": {}, "pow2_offsets": True})
+    return out
+
+
+STALENESS = {
+    "constant": {"staleness_fn": "constant"},
+    "polynomial": {"staleness_fn": "polynomial", "staleness_fn_kwargs": {"a": 0.5}},
+    "hinge": {"staleness_fn": "hinge", "staleness_fn_kwargs": {"a": 10, "b": 2}},
+}
+# (client, download-before-upload?) arrival script: staleness between 0 and 5
+ASYNC_SCRIPT = [(0, True), (1, True), (2, False), (0, False), (0, True), (1, False), (2, True),
+                (1, True)]
+
+
+def async_scenarios() -> List[Dict]:
+    out = []
+    for sname, scfg in STALENESS.items():
+        for gb, with_model, optmem in itertools.product((False, True), (False, True), (True, False)):
+            cfg = dict(scfg, alpha=0.9, num_clients=3, gradient_based=gb, optimize_memory=optmem)
+            out.append({"id": f"FedAsync-{sname}-{'grad' if gb else 'model'}-"
+                              f"{'model' if with_model else 'nomodel'}-{'opt' if optmem else 'orig'}",
+                        "kind": "async", "cls": "FedAsyncAggregator", "spec": "toy",
+                        "model": with_model, "cfg": cfg, "script": ASYNC_SCRIPT, "sample_sizes": {}})
+    out.append({"id": "FedAsync-samplesize-ragged", "kind": "async", "cls": "FedAsyncAggregator",
+                "spec": "ragged", "model": False,
+                "cfg": dict(STALENESS["polynomial"], alpha=0.9, num_clients=3,
+                            client_weights_mode="sample_size"),
+                "script": ASYNC_SCRIPT, "sample_sizes": {0: 10, 1: 25, 2: 7}})
+    for gb, with_model in itertools.product((False, True), (False, True)):
+        cfg = dict(STALENESS["polynomial"], alpha=0.9, num_clients=3, K=3, gradient_based=gb)
+        out.append({"id": f"FedBuff-{'grad' if gb else 'model'}-{'model' if with_model else 'nomodel'}",
+                    "kind": "async", "cls": "FedBuffAggregator", "spec": "toy", "model": with_model,
+                    "cfg": cfg, "script": ASYNC_SCRIPT[:7], "sample_sizes": {}})
+    out.append({"id": "FedBuff-ragged-K2", "kind": "async", "cls": "FedBuffAggregator",
+                "spec": "ragged", "model": False,
+                "cfg": dict(STALENESS["hinge"], alpha=0.9, num_clients=3, K=2,
+                            client_weights_mode="sample_size"),
+                "script": ASYNC_SCRIPT, "sample_sizes": {0: 10, 1: 25, 2: 7}})
+    return out
+
+
+# The reference evaluates sqrt(v) with MKL's vector-math sqrt (torch.sqrt on an MKL build),
+# which is within 1 ulp but NOT correctly rounded (measured: 0.65 % of values one ulp low), and
+# whose bits depend on the host CPU's approximation instructions.  The oracle and the HIP
+# kernels use the IEEE correctly rounded sqrt, so aggregators with a sqrt in their step are
+# compared with the reference under a tolerance; everything else is compared bit for bit.
+SQRT_CLASSES = ("FedAdamAggregator", "FedYogiAggregator", "FedAdagradAggregator")
+REFERENCE_RTOL = 1e-6
+
+
+def reference_rtol(sc: Dict):
+    """None = bit-exact against the reference's vectors; else max |diff| / max |tensor|."""
+    return REFERENCE_RTOL if sc["cls"] in SQRT_CLASSES else None
+
+
+def all_scenarios() -> List[Dict]:
+    return sync_scenarios() + async_scenarios()
+
+
+def _state_snapshots(agg) -> List[Tuple[str, Dict]]:
+    out = []
+    for attr in ("m_vector", "v_vector"):
+        d = getattr(agg, attr, None)
+        if d:
+            out.append((attr, _snap(d)))
+    return out
+
+
+def run_scenario(factory: Callable, sc: Dict) -> List[Tuple[str, Dict[str, np.ndarray]]]:
+    spec = SPECS[sc["spec"]]
+    model = ToyModel() if sc["model"] else None
+    agg = factory(sc["cls"], model, dict(sc["cfg"]))
+    for cid, n in sc["sample_sizes"].items():
+        agg.set_client_sample_size(cid, n)
+    rec: List[Tuple[str, Dict]] = []
+    if model is not None:
+        rec.append(("initial", _snap(agg.get_parameters())))
+    if sc["kind"] == "sync":
+        for r, K in enumerate(sc["rounds"]):
+            cids = [(r + j) % max(6, K) for j in range(K)]
+            local = {}
+            for cid in cids:
+                st = make_state(spec, seed=1000 + 97 * r + cid)
+                if sc.get("pow2_offsets"):
+                    # every client sits exactly 2^-10 above the current global model
+                    for name in st:
+                        if st[name].dtype != torch.float32:
+                            continue
+                        if rec and name in rec[-1][1]:
+                            ref = torch.from_numpy(rec[-1][1][name])
+                        else:
+                            ref = torch.from_numpy(synth.fill(
+                                st[name].numel(), 7 * 131 + _name_seed(name),
+                                scale=0.05).reshape(tuple(st[name].shape)))
+                        st[name] = (ref + 2.0 ** -10).to(torch.float32)
+                local[cid] = st
+            out = agg.aggregate(local, round_tag={c: r for c in cids})
+            for lbl, d in _state_snapshots(agg):
+                rec.append((f"round{r}.{lbl}", d))
+            rec.append((f"round{r}", _snap(out)))
+        rec.append(("final_get_parameters", _snap(agg.get_parameters())))
+    else:
+        gb = sc["cfg"].get("gradient_based", False)
+        for i, (cid, download) in enumerate(sc["script"]):
+            if download:
+                # without a model the first download raises (and still records the client's step)
+                try:
+                    rec.append((f"arrival{i}.download", _snap(agg.get_parameters(client_id=cid))))
+                except ValueError as e:
+                    rec.append((f"arrival{i}.download.ValueError",
+                                {"message": np.frombuffer(str(e).encode(), dtype=np.uint8).copy()}))
+            st = make_state(spec, seed=2000 + 31 * i + cid, gradient=gb, scale=0.01 if gb else 0.02)
+            out = agg.aggregate(cid, st, local_steps=5)
+            rec.append((f"arrival{i}", _snap(out)))
+        rec.append(("final_get_parameters", _snap(agg.get_parameters())))
+    return rec

@@ -1,0 +1,129 @@
+"""The device aggregators, driven through the reference's plugin interface, against
+(1) the golden vectors produced by the reference's own classes and (2) the CPU oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util
+import scenarios as S
+from oracle import aggregators as OA
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_factory(cls, model, cfg):
+    import appfl_amd.aggregator as A
+    return getattr(A, cls)(model, cfg, None)
+
+
+def oracle_factory(cls, model, cfg):
+    return OA.ORACLES[cls](model, cfg, None)
+
+
+@pytest.mark.parametrize("sc", S.all_scenarios(), ids=lambda s: s["id"])
+def test_matches_reference_golden(sc):
+    """Bit-exact against the reference for every aggregator without a sqrt in its step;
+    within 1e-6 of the tensor scale for FedAdam / FedYogi / FedAdagrad (see scenarios.py)."""
+    golden_util.check_records(sc["id"], S.run_scenario(hip_factory, sc), S.reference_rtol(sc))
+
+
+@pytest.mark.parametrize("sc", S.all_scenarios(), ids=lambda s: s["id"])
+def test_matches_oracle_bit_for_bit(sc):
+    """Every aggregator, sqrt or not: identical bits to the CPU oracle on every record."""
+    got = S.run_scenario(hip_factory, sc)
+    want = S.run_scenario(oracle_factory, sc)
+    assert [l for l, _ in got] == [l for l, _ in want]
+    for (label, a), (_, b) in zip(got, want):
+        assert list(a) == list(b), f"{sc['id']}/{label}: key order {list(a)} vs {list(b)}"
+        for k in a:
+            assert golden_util.same_bits(a[k], b[k]), f"{sc['id']}/{label}/{k} differs from the oracle"
+
+
+def test_output_is_fresh_cpu_tensors_and_inputs_untouched():
+    import appfl_amd.aggregator as A
+    agg = A.FedAsyncAggregator(None, {"alpha": 0.5, "num_clients": 2}, None)
+    x = S.make_state(S.TOY, seed=11)
+    keep = {k: v.clone() for k, v in x.items()}
+    out1 = agg.aggregate(0, x)
+    out2 = agg.aggregate(1, S.make_state(S.TOY, seed=12))
+    for k in x:
+        assert torch.equal(x[k], keep[k]), "client tensors must not be modified"
+        assert not out1[k].is_cuda and out1[k].dtype == x[k].dtype and out1[k].shape == x[k].shape
+    out1["fc.bias"].add_(1.0)                 # caller may mutate what it got
+    out3 = agg.get_parameters()
+    assert torch.equal(out3["fc.bias"], out2["fc.bias"])
+
+
+def test_missing_and_extra_client_keys():
+    """A client lacking a weighted entry contributes nothing to it, extra keys are ignored, a
+    missing plain-mean entry is a KeyError (fedavg_aggregator.py:360-361, :289)."""
+    import appfl_amd.aggregator as A
+    cfg = {"client_weights_mode": "equal"}
+    agg, ora = A.FedAvgAggregator(None, cfg, None), OA.OracleFedAvg(None, cfg, None)
+    a, b, c = (S.make_state(S.TOY, seed=s) for s in (21, 22, 23))
+    for f in (agg, ora):
+        f.aggregate({0: {k: v.clone() for k, v in a.items()}, 1: {k: v.clone() for k, v in b.items()}})
+    b2 = {k: v.clone() for k, v in b.items() if k != "fc.weight"}
+    b2["not.in.global"] = torch.ones(3)
+    got = agg.aggregate({0: {k: v.clone() for k, v in c.items()}, 1: b2})
+    want = ora.aggregate({0: {k: v.clone() for k, v in c.items()}, 1: {k: v.clone() for k, v in b2.items()}})
+    for k in want:
+        assert golden_util.same_bits(got[k].numpy(), want[k]), k
+    b3 = {k: v.clone() for k, v in b.items() if k != "bn.num_batches_tracked"}
+    with pytest.raises(KeyError):
+        agg.aggregate({0: {k: v.clone() for k, v in c.items()}, 1: b3})
+
+
+def test_errors_match_reference():
+    import appfl_amd.aggregator as A
+    with pytest.raises(ValueError, match="Model is not provided to the aggregator."):
+        A.FedAvgAggregator(None, {}, None).get_parameters()
+    with pytest.raises(NotImplementedError):
+        A.FedAsyncAggregator(None, {"staleness_fn": "nope"}, None)
+    with pytest.raises(AttributeError):
+        A.FedBuffAggregator(None, {}, None)          # K is required
+    agg = A.FedAdamAggregator(None, {"server_learning_rate": 0.1}, None)
+    with pytest.raises(AttributeError):
+        agg.aggregate({0: S.make_state(S.TOY, seed=1), 1: S.make_state(S.TOY, seed=2)})
+
+
+def test_user_subclass_overriding_compute_steps():
+    """A plugin that post-processes self.step (as the reference's subclasses do) still works:
+    aggregate() falls back to compute_steps() -> apply."""
+    import appfl_amd.aggregator as A
+
+    class Halved(A.FedAvgAggregator):
+        def compute_steps(self, local_models):
+            super().compute_steps(local_models)
+            for name in self.step:
+                self.step[name].mul_(0.5)
+
+    a, b = S.make_state(S.TOY, seed=31), S.make_state(S.TOY, seed=32)
+    plain, half = A.FedAvgAggregator(None, {}, None), Halved(None, {}, None)
+    # first round without a model: the global state starts as client 0's tensors
+    o1 = plain.aggregate({0: {k: v.clone() for k, v in a.items()}, 1: {k: v.clone() for k, v in b.items()}})
+    o2 = half.aggregate({0: {k: v.clone() for k, v in a.items()}, 1: {k: v.clone() for k, v in b.items()}})
+    for k in ("conv.weight", "fc.weight"):
+        full = (o1[k] - a[k]).numpy()
+        got = (o2[k] - a[k]).numpy()
+        assert np.allclose(got, 0.5 * full, rtol=1e-4, atol=1e-7), k
+    assert torch.equal(o1["bn.num_batches_tracked"], o2["bn.num_batches_tracked"])
+
+
+def test_chunked_get_parameters():
+    import appfl_amd.aggregator as A
+    agg = A.FedAvgAggregator(None, {}, None)
+    agg.set_model_chunk_size(1024)
+    agg.aggregate({0: S.make_state(S.TOY, seed=1), 1: S.make_state(S.TOY, seed=2)})
+    whole = agg.get_parameters()
+    first, meta = agg.get_parameters(_request_chunked=True)
+    assert meta["_chunk_idx"] == 0 and meta["_total_chunks"] >= 2
+    seen = {}
+    for i in range(meta["_total_chunks"]):
+        part, m = agg.get_parameters(_chunk_id=i)
+        assert m["_chunk_keys"] == sorted(m["_chunk_keys"]) and list(part) == m["_chunk_keys"]
+        seen.update(part)
+    assert sorted(seen) == sorted(whole)
+    for k in whole:
+        assert torch.equal(seen[k], whole[k])
