@@ -161,6 +161,16 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
             self._flats["i32"][:lay.count[MEAN_I32]].copy_(
                 self._slab.row_view(0, lay.seg_byte[MEAN_I32], lay.count[MEAN_I32], torch.int32))
 
+    def _launch_arrival(self, alpha_t: float) -> None:
+        """Enqueue the kernels of one arrival staged in row 0 of the slab."""
+        n_step = self._layout.count[STEP]
+        if n_step:
+            ops.async_mix(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t,
+                          self._flats["f32"],
+                          gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
+                          sub_form=bool(self.optimize_memory), n=n_step)
+        self._copy_non_step_entries()
+
     # -- aggregate: fedasync_aggregator.py:103-184 ------------------------------------------------
     def aggregate(self, client_id: Union[str, int], local_model: Union[Dict, OrderedDict],
                   **kwargs) -> Dict:
@@ -168,14 +178,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
             if self._layout is None:
                 self._init_global_state(local_model)
             self._upload(local_model)
-            alpha_t = self._alpha_t(client_id)
-            n_step = self._layout.count[STEP]
-            if n_step:
-                ops.async_mix(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t,
-                              self._flats["f32"],
-                              gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
-                              sub_form=bool(self.optimize_memory), n=n_step)
-            self._copy_non_step_entries()
+            self._launch_arrival(self._alpha_t(client_id))
             self.global_step += 1
             self.client_step[client_id] = self.global_step
             out = self._download()
@@ -194,6 +197,28 @@ class FedBuffAggregator(FedAsyncAggregator):
         self.buff_size = 0
         self.K = cfg_require(self.aggregator_configs, "K")
 
+    def _launch_arrival(self, alpha_t: float, first: bool, flush: bool) -> None:
+        """Enqueue the kernels of one buffered arrival staged in row 0 of the slab."""
+        lay = self._layout
+        n_step = lay.count[STEP]
+        g, st = self._flats, self._step_flats
+        if n_step:
+            ops.buff_accum(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t, g["f32"],
+                           st["f32"], first,
+                           gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
+                           flush=flush, n=n_step)
+        # entries outside the step are summed raw and flushed as a mean (:146-152, :84-86)
+        for cls, key, dtype, lo in ((MEAN_F32, "f32", torch.float32, n_step),
+                                    (MEAN_I64, "i64", torch.int64, 0),
+                                    (MEAN_I32, "i32", torch.int32, 0)):
+            cnt = lay.count[cls]
+            if not cnt:
+                continue
+            ops.buff_accum_raw(self._slab.row_view(0, lay.seg_byte[cls], cnt, dtype),
+                               st[key][lo:lo + cnt], first, n=cnt)
+            if flush:
+                ops.buff_flush_mean(g[key][lo:lo + cnt], st[key][lo:lo + cnt], self.K, n=cnt)
+
     # -- aggregate: fedbuff_aggregator.py:25-105 with compute_steps :107-158 ------------------------
     def aggregate(self, client_id: Union[str, int], local_model: Union[Dict, OrderedDict],
                   **kwargs) -> Dict:
@@ -205,26 +230,8 @@ class FedBuffAggregator(FedAsyncAggregator):
                 self._step_flats = lay.alloc_state(self.device)
             self._upload(local_model)
             first = self.buff_size == 0            # :116-124 zero the buffer
-            alpha_t = self._alpha_t(client_id)
             flush = self.buff_size + 1 == self.K   # :74-75
-            n_step = lay.count[STEP]
-            g, st = self._flats, self._step_flats
-            if n_step:
-                ops.buff_accum(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t, g["f32"],
-                               st["f32"], first,
-                               gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
-                               flush=flush, n=n_step)
-            # entries outside the step are summed raw and flushed as a mean (:146-152, :84-86)
-            for cls, key, dtype, lo in ((MEAN_F32, "f32", torch.float32, n_step),
-                                        (MEAN_I64, "i64", torch.int64, 0),
-                                        (MEAN_I32, "i32", torch.int32, 0)):
-                cnt = lay.count[cls]
-                if not cnt:
-                    continue
-                ops.buff_accum_raw(self._slab.row_view(0, lay.seg_byte[cls], cnt, dtype),
-                                   st[key][lo:lo + cnt], first, n=cnt)
-                if flush:
-                    ops.buff_flush_mean(g[key][lo:lo + cnt], st[key][lo:lo + cnt], self.K, n=cnt)
+            self._launch_arrival(self._alpha_t(client_id), first, flush)
             self.buff_size += 1
             if flush:
                 self.global_step += 1

@@ -218,6 +218,41 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self.step = {e.name: self._step_flat[e.offset:e.offset + e.numel].view(e.shape)
                          for e in lay.entries if e.cls == STEP}
 
+    def _launch_round(self, K: int, weights, fused: bool = True, events=None) -> None:
+        """Enqueue one round's kernels over the K staged rows: the fused weighted-step /
+        optimizer / apply kernel (or, un-fused, the apply of a step computed by compute_steps),
+        then the plain means of the entries that bypass the step.  `events` = (start, end)
+        torch.cuda.Event pair recorded around the fused kernel (benchmark timing)."""
+        lay = self._layout
+        n_step = lay.count[STEP]
+        g = self._flats["f32"]
+        if fused:
+            if n_step:
+                self._ensure_moments()
+                ws = None
+                if K > ops.kchunk():
+                    if self._step_flat is None:
+                        self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+                    ws = self._step_flat
+                if events:
+                    events[0].record()
+                ops.reduce_opt(self._rows(K, 0), weights, g, self._m, self._v, self._OPT,
+                               step_ws=ws, n=n_step, **self._hyper())
+                if events:
+                    events[1].record()
+        else:
+            for e in lay.entries:
+                if e.name in self.step:
+                    ops.apply_step(lay.view(self._flats, e.name).view(-1),
+                                   self.step[e.name].contiguous().view(-1))
+        # entries that bypass the step: plain mean over clients (fedavg_aggregator.py:285-296)
+        if lay.count[MEAN_F32]:
+            ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), g[n_step:], n=lay.count[MEAN_F32])
+        if lay.count[MEAN_I64]:
+            ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
+        if lay.count[MEAN_I32]:
+            ops.mean(self._rows(K, lay.seg_byte[MEAN_I32]), self._flats["i32"], n=lay.count[MEAN_I32])
+
     # -- aggregate: fedavg_aggregator.py:150-320 -----------------------------------------------------
     def aggregate(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict]], **kwargs) -> Dict:
         """Weighted average of the clients' models (then the server-optimizer step); returns the
@@ -236,35 +271,12 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             first = next(iter(local_models.values()))
             if self._layout is None:
                 self._init_global_state(first)
-            lay = self._layout
             K = len(local_models)
             self._stage(local_models)
-            n_step = lay.count[STEP]
-            g = self._flats["f32"]
             fused = getattr(type(self).compute_steps, "_appfl_amd_native", False)
-            if fused:
-                if n_step:
-                    self._ensure_moments()
-                    ws = None
-                    if K > ops.kchunk():
-                        if self._step_flat is None:
-                            self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
-                        ws = self._step_flat
-                    ops.reduce_opt(self._rows(K, 0), self._client_weights(local_models), g,
-                                   self._m, self._v, self._OPT, step_ws=ws, n=n_step, **self._hyper())
-            else:
+            if not fused:
                 self.compute_steps(local_models)          # user override (may call super())
-                for e in lay.entries:
-                    if e.name in self.step:
-                        ops.apply_step(lay.view(self._flats, e.name).view(-1),
-                                       self.step[e.name].contiguous().view(-1))
-            # entries that bypass the step: plain mean over clients (fedavg_aggregator.py:285-296)
-            if lay.count[MEAN_F32]:
-                ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), g[n_step:], n=lay.count[MEAN_F32])
-            if lay.count[MEAN_I64]:
-                ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
-            if lay.count[MEAN_I32]:
-                ops.mean(self._rows(K, lay.seg_byte[MEAN_I32]), self._flats["i32"], n=lay.count[MEAN_I32])
+            self._launch_round(K, self._client_weights(local_models), fused)
             self.step = {}
             self._staged_for = None
             out = self._download()

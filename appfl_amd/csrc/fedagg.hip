@@ -258,11 +258,24 @@ __device__ __forceinline__ int32_t mean_finish(int32_t s, float kf) {
     return static_cast<int32_t>(static_cast<float>(s) / kf);
 }
 
+// The client values of an element are loaded kMeanBatch at a time (independent loads in
+// flight) and then added in client order; with few elements the kernel is latency-bound, so the
+// batch depth, not the thread count, sets its duration.
+constexpr int kMeanBatch = 16;
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mean_kernel(const MeanArgs<T> a) {
     for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < a.n; i += gridDim.x * kThreads) {
         T s = a.sum_in ? a.sum_in[i] : static_cast<T>(0);
-        for (int k = 0; k < a.K; ++k) s = s + __builtin_nontemporal_load(a.x[k] + i);
+        int k = 0;
+        for (; k + kMeanBatch <= a.K; k += kMeanBatch) {
+            T x[kMeanBatch];
+#pragma unroll
+            for (int u = 0; u < kMeanBatch; ++u) x[u] = __builtin_nontemporal_load(a.x[k + u] + i);
+#pragma unroll
+            for (int u = 0; u < kMeanBatch; ++u) s = s + x[u];
+        }
+        for (; k < a.K; ++k) s = s + __builtin_nontemporal_load(a.x[k] + i);
         a.g[i] = a.last ? mean_finish(s, a.Kall) : s;
     }
 }
