@@ -33,6 +33,21 @@ from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_req
                               resolve_device)
 
 
+class _ChunkState:
+    """Global state of one chunk of a streamed aggregation (its own layout, vectors, slab)."""
+
+    def __init__(self, layout, flats, slab):
+        self.layout, self.flats, self.slab = layout, flats, slab
+
+
+def _download_flats(lay: Layout, flats: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Fresh CPU copy of flat state vectors: one D2H copy per dtype, entries are views of it."""
+    host = {}
+    for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
+        host[key] = flats[key][:n].cpu() if n else torch.empty(0, dtype=flats[key].dtype)
+    return lay.views(host)
+
+
 def _native(fn):
     """Marks a compute_steps implementation of this package (a user override lacks the mark and
     switches `aggregate` to the un-fused compute_steps -> apply sequence)."""
@@ -71,6 +86,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._v: Optional[torch.Tensor] = None
         self._step_flat: Optional[torch.Tensor] = None
         self._staged_for = None
+        self._chunks: Dict[tuple, "_ChunkState"] = {}    # streamed aggregation, one per key set
         self._init_lock()
 
     # -- attributes the reference exposes -------------------------------------------------------
@@ -78,7 +94,12 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
     def global_state(self) -> Optional[Dict[str, torch.Tensor]]:
         """{name: device tensor} views of the flat global state (None before the first round)."""
         if self._layout is None:
-            return None
+            if not self._chunks:
+                return None
+            merged = {}
+            for st in self._chunks.values():
+                merged.update(st.layout.views(st.flats))
+            return merged
         return self._layout.views(self._flats)
 
     def _moment_views(self, flat) -> Dict[str, torch.Tensor]:
@@ -131,6 +152,11 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     meta = {"_chunk_idx": chunk_idx, "_total_chunks": len(chunks),
                             "_chunk_keys": keys}
                     return (result, meta)
+            if self._layout is None and self._chunks:
+                merged = {}
+                for st in self._chunks.values():
+                    merged.update(_download_flats(st.layout, st.flats))
+                return merged
             if self._layout is None:
                 if self.model is None:
                     raise ValueError("Model is not provided to the aggregator.")
@@ -160,13 +186,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         lay = self._layout
         if names is not None:
             return {n: lay.view(self._flats, n).cpu() for n in names if n in lay.by_name}
-        host = {}
-        for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
-            if n:
-                host[key] = self._flats[key][:n].cpu()
-            else:
-                host[key] = torch.empty(0, dtype=self._flats[key].dtype)
-        return lay.views(host)
+        return _download_flats(lay, self._flats)
 
     def _client_weights(self, local_models) -> list:
         """fedavg_aggregator.py:343-358."""
@@ -261,8 +281,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         assert not (secure_enabled and "_chunk_idx" in kwargs), (
             "Secure aggregation does not support chunked aggregation yet.")
         if "_chunk_idx" in kwargs:
-            raise NotImplementedError(
-                "streamed (chunked) aggregation is not implemented on the MI355X path yet")
+            return self._aggregate_chunk(local_models, **kwargs)
         if secure_enabled and all(isinstance(m, dict) and m.get("type") == "masked_update_flat"
                                   for m in local_models.values()):
             raise NotImplementedError(
@@ -282,6 +301,49 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             out = self._download()
             self._sync_model(self.model, out)
             return out
+
+
+    # -- streamed aggregation: fedavg_aggregator.py:406-497 ------------------------------------------
+    def _aggregate_chunk(self, local_models, **kwargs) -> Dict:
+        """One chunk of a streamed aggregation: only the keys in `_chunk_keys`, each chunk with
+        its own device-resident state started from the first client's tensors (:416-423).  As in
+        the reference every non-integer key takes the plain FedAvg step here -- no
+        named-parameter test (:466-471) and no server optimizer (subclasses do not override
+        this path)."""
+        chunk_keys = list(list(kwargs["_chunk_keys"].values())[0])
+        with self._lock:
+            first = next(iter(local_models.values()))
+            tag = tuple(chunk_keys)
+            st = self._chunks.get(tag)
+            if st is None:
+                init = {k: first[k] for k in chunk_keys if k in first}
+                lay = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()], None)
+                flats = lay.alloc_state(self.device)
+                with torch.no_grad():
+                    for n, t in init.items():
+                        lay.view(flats, n).copy_(t.detach())
+                st = _ChunkState(lay, flats, ClientSlab(lay, self.device))
+                self._chunks[tag] = st
+            lay, K = st.layout, len(local_models)
+            st.slab.reserve(K)
+            st.slab.begin_round()
+            for k, model in enumerate(local_models.values()):
+                st.slab.upload(k, model, fill_missing_from=st.flats["f32"])
+            st.slab.end_round()
+            rows = lambda off: [st.slab.row_ptr(k) + off for k in range(K)]
+            if lay.count[STEP]:
+                ws = None
+                if K > ops.kchunk():
+                    ws = torch.empty(lay.count[STEP], dtype=torch.float32, device=self.device)
+                ops.reduce_opt(rows(0), self._client_weights(local_models), st.flats["f32"],
+                               step_ws=ws, n=lay.count[STEP])
+            if lay.count[MEAN_I64]:
+                ops.mean(rows(lay.seg_byte[MEAN_I64]), st.flats["i64"], n=lay.count[MEAN_I64])
+            if lay.count[MEAN_I32]:
+                ops.mean(rows(lay.seg_byte[MEAN_I32]), st.flats["i32"], n=lay.count[MEAN_I32])
+            out = _download_flats(lay, st.flats)
+            self._sync_model(self.model, out)        # partial update (:447-452)
+            return {k: out[k] for k in chunk_keys if k in out}
 
 
 class FedAvgMAggregator(FedAvgAggregator):

@@ -125,8 +125,39 @@ class OracleFedAvg(OracleBase):
                     diff = to_np(model[name]).astype(F32, copy=False) - self.global_state[name]
                     self.step[name] = self.step[name] + diff * wk
 
+    def _aggregate_chunk(self, local_models, **kwargs):
+        """fedavg_aggregator.py:406-497: streamed aggregation of the keys in `_chunk_keys`."""
+        chunk_keys = list(list(kwargs["_chunk_keys"].values())[0])
+        if self.global_state is None:
+            self.global_state = {}
+        first = next(iter(local_models.values()))
+        for key in chunk_keys:
+            if key not in self.global_state and key in first:
+                self.global_state[key] = first[key].copy()
+        step = {}
+        for key in chunk_keys:                       # :464-471 (no named-parameter test)
+            if key in self.global_state and self.global_state[key].dtype not in _INT:
+                step[key] = np.zeros_like(self.global_state[key])
+        w = self._weights(local_models)
+        for cid, model in local_models.items():
+            wk = _f32(w[cid])
+            for key in chunk_keys:
+                if key in step and key in model:
+                    step[key] = step[key] + (model[key] - self.global_state[key]) * wk
+        for key in chunk_keys:
+            if key in step:
+                self.global_state[key] = self.global_state[key] + step[key]
+            else:
+                s = np.zeros_like(self.global_state[key])
+                for model in local_models.values():
+                    s = s + model[key]
+                self.global_state[key] = _int_div(s, len(local_models))
+        return {k: self.global_state[k].copy() for k in chunk_keys}
+
     def aggregate(self, local_models, **kwargs):
         local_models = {c: {k: to_np(v) for k, v in m.items()} for c, m in local_models.items()}
+        if "_chunk_idx" in kwargs:
+            return self._aggregate_chunk(local_models, **kwargs)
         first = next(iter(local_models.values()))
         if self.global_state is None:
             # fedavg_aggregator.py:228-271

@@ -192,8 +192,46 @@ def reference_rtol(sc: Dict):
     return REFERENCE_RTOL if sc["cls"] in SQRT_CLASSES else None
 
 
+def chunked_scenarios() -> List[Dict]:
+    """Streamed aggregation (fedavg_aggregator.py:406-497): every round arrives as chunks of
+    name-sorted keys; FedAdam is included because the reference applies no server optimizer on
+    this path."""
+    out = []
+    for cls, with_model in (("FedAvgAggregator", False), ("FedAvgAggregator", True),
+                            ("FedAdamAggregator", False)):
+        out.append({"id": f"{cls[:-10]}-chunked-{'model' if with_model else 'nomodel'}",
+                    "kind": "chunked", "cls": cls, "spec": "toy", "model": with_model,
+                    "cfg": dict(HP[cls], client_weights_mode="sample_size"),
+                    "rounds": [2, 3], "chunk_bytes": 600,
+                    "sample_sizes": {c: 4 + 5 * c for c in range(6)}})
+    return out
+
+
+def chunk_keys_by_size(spec: Dict, max_bytes: int) -> List[List[str]]:
+    """misc/memory_utils.py:317-379: names sorted, greedy fill, oversized tensors alone."""
+    item = {"f32": 4, "i64": 8, "i32": 4}
+    chunks, cur, size = [], [], 0
+    for key in sorted(spec):
+        shape, kind = spec[key]
+        nbytes = (int(np.prod(shape)) if shape else 1) * item[kind]
+        if nbytes > max_bytes:
+            if cur:
+                chunks.append(cur)
+                cur, size = [], 0
+            chunks.append([key])
+            continue
+        if size + nbytes > max_bytes and cur:
+            chunks.append(cur)
+            cur, size = [], 0
+        cur.append(key)
+        size += nbytes
+    if cur:
+        chunks.append(cur)
+    return chunks
+
+
 def all_scenarios() -> List[Dict]:
-    return sync_scenarios() + async_scenarios()
+    return sync_scenarios() + async_scenarios() + chunked_scenarios()
 
 
 def _state_snapshots(agg) -> List[Tuple[str, Dict]]:
@@ -237,6 +275,18 @@ def run_scenario(factory: Callable, sc: Dict) -> List[Tuple[str, Dict[str, np.nd
             for lbl, d in _state_snapshots(agg):
                 rec.append((f"round{r}.{lbl}", d))
             rec.append((f"round{r}", _snap(out)))
+        rec.append(("final_get_parameters", _snap(agg.get_parameters())))
+    elif sc["kind"] == "chunked":
+        chunks = chunk_keys_by_size(spec, sc["chunk_bytes"])
+        for r, K in enumerate(sc["rounds"]):
+            cids = [(r + j) % 6 for j in range(K)]
+            states = {cid: make_state(spec, seed=3000 + 97 * r + cid) for cid in cids}
+            for ci, keys in enumerate(chunks):
+                local = {cid: {k: states[cid][k].clone() for k in keys} for cid in cids}
+                out = agg.aggregate(local, _chunk_idx={c: ci for c in cids},
+                                    _total_chunks={c: len(chunks) for c in cids},
+                                    _chunk_keys={c: list(keys) for c in cids})
+                rec.append((f"round{r}.chunk{ci}", _snap(out)))
         rec.append(("final_get_parameters", _snap(agg.get_parameters())))
     else:
         gb = sc["cfg"].get("gradient_based", False)
