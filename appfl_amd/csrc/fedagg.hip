@@ -42,6 +42,7 @@ struct ReduceArgs {
     int K;
     int last;   // 1: run the optimizer epilogue and the apply
     int apply;  // 1: write g (0 = step-only mode)
+    int wt;     // 1: results leave with write-through (sc0 sc1) stores
     Hyper h;
 };
 
@@ -93,6 +94,24 @@ __device__ __forceinline__ void store_state<1>(float* p, unsigned i, const Pack<
     p[i] = r.e[0];
 }
 
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+// Result store of the 128-bit kernels: optionally write-through (sc0 sc1), which keeps the
+// result lines from lingering dirty in L2 and trickling out between the streaming reads.
+__device__ __forceinline__ void store_result(float* p, unsigned i, const Pack<4>& r, int wt) {
+    if (wt) {
+        f4 t;
+        t.x = r.e[0]; t.y = r.e[1]; t.z = r.e[2]; t.w = r.e[3];
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rs, i * 16u, 0, 17);
+    } else {
+        store_state<4>(p, i, r);
+    }
+}
+__device__ __forceinline__ void store_result(float* p, unsigned i, const Pack<1>& r, int) {
+    store_state<1>(p, i, r);
+}
+
 __device__ __forceinline__ float sign_f32(float d) {
     // torch.sign: (0 < d) - (d < 0); NaN and both zeros give 0.
     return static_cast<float>(static_cast<int>(0.0f < d) - static_cast<int>(d < 0.0f));
@@ -130,29 +149,27 @@ __device__ __forceinline__ float optimizer_step(float step, float& m, float& v, 
     return num / den;
 }
 
-// One tile = kThreads * VPT vectors; a thread owns vectors tile_base + p * kThreads + tid.
-// In the one partial tile (GUARD) out-of-range threads redo the last vector's loads and skip
-// the stores, so the instruction stream is the unguarded one.
-template <int OPT, int VEC, int VPT, int U, bool NT, bool GUARD>
-__device__ __forceinline__ void reduce_tile(const ReduceArgs& a, unsigned base) {
-    unsigned idx[VPT];
-    bool ok[VPT];
-#pragma unroll
-    for (int p = 0; p < VPT; ++p) {
-        unsigned i = base + p * kThreads + threadIdx.x;
-        ok[p] = !GUARD || i < a.n;
-        idx[p] = ok[p] ? i : a.n - 1;
-    }
+// Registers a thread holds for one tile (VPT vectors of VEC floats each).
+template <int VEC, int VPT>
+struct TileRegs {
+    Pack<VEC> g[VPT], s[VPT], m[VPT], v[VPT];
+};
+
+// Folds the K clients of this launch into the step of the vectors idx[0..VPT) and, on the last
+// client chunk, runs the optimizer epilogue and forms g + step.  Everything stays in registers;
+// the caller decides how the results reach memory.
+template <int OPT, int VEC, int VPT, int U, bool NT>
+__device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&idx)[VPT],
+                                          TileRegs<VEC, VPT>& r) {
     const float* gsrc = a.apply ? a.g : a.g_ro;
-    Pack<VEC> g[VPT], s[VPT];
 #pragma unroll
     for (int p = 0; p < VPT; ++p) {
-        g[p] = load_state<VEC>(gsrc, idx[p]);
+        r.g[p] = load_state<VEC>(gsrc, idx[p]);
         if (a.step_in) {
-            s[p] = load_state<VEC>(a.step_in, idx[p]);
+            r.s[p] = load_state<VEC>(a.step_in, idx[p]);
         } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) s[p].e[j] = 0.0f;
+            for (int j = 0; j < VEC; ++j) r.s[p].e[j] = 0.0f;
         }
     }
     int k = 0;
@@ -169,9 +186,9 @@ __device__ __forceinline__ void reduce_tile(const ReduceArgs& a, unsigned base) 
             for (int p = 0; p < VPT; ++p) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    float d = xv[u][p].e[j] - g[p].e[j];
+                    float d = xv[u][p].e[j] - r.g[p].e[j];
                     float wd = d * wk;
-                    s[p].e[j] = s[p].e[j] + wd;
+                    r.s[p].e[j] = r.s[p].e[j] + wd;
                 }
             }
         }
@@ -183,43 +200,60 @@ __device__ __forceinline__ void reduce_tile(const ReduceArgs& a, unsigned base) 
             Pack<VEC> xv = load_stream<VEC, NT>(a.x[k], idx[p]);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float d = xv.e[j] - g[p].e[j];
+                float d = xv.e[j] - r.g[p].e[j];
                 float wd = d * wk;
-                s[p].e[j] = s[p].e[j] + wd;
+                r.s[p].e[j] = r.s[p].e[j] + wd;
             }
         }
     }
-    if (!a.last) {
-#pragma unroll
-        for (int p = 0; p < VPT; ++p)
-            if (ok[p]) store_state<VEC>(a.step_out, idx[p], s[p]);
-        return;
-    }
+    if (!a.last) return;
 #pragma unroll
     for (int p = 0; p < VPT; ++p) {
         if (OPT != FA_OPT_NONE) {
-            Pack<VEC> m, v;
-            v = load_state<VEC>(a.v, idx[p]);
-            if (OPT != FA_OPT_AVGM) m = load_state<VEC>(a.m, idx[p]);
+            r.v[p] = load_state<VEC>(a.v, idx[p]);
+            if (OPT != FA_OPT_AVGM) r.m[p] = load_state<VEC>(a.m, idx[p]);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float mj = (OPT != FA_OPT_AVGM) ? m.e[j] : 0.0f;
-                s[p].e[j] = optimizer_step<OPT>(s[p].e[j], mj, v.e[j], a.h);
-                if (OPT != FA_OPT_AVGM) m.e[j] = mj;
-            }
-            if (ok[p]) {
-                store_state<VEC>(a.v, idx[p], v);
-                if (OPT != FA_OPT_AVGM) store_state<VEC>(a.m, idx[p], m);
+                float mj = (OPT != FA_OPT_AVGM) ? r.m[p].e[j] : 0.0f;
+                r.s[p].e[j] = optimizer_step<OPT>(r.s[p].e[j], mj, r.v[p].e[j], a.h);
+                if (OPT != FA_OPT_AVGM) r.m[p].e[j] = mj;
             }
         }
-        if (ok[p]) {
-            if (a.step_out) store_state<VEC>(a.step_out, idx[p], s[p]);
-            if (a.apply) {
+        if (a.apply) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) g[p].e[j] = g[p].e[j] + s[p].e[j];
-                store_state<VEC>(a.g, idx[p], g[p]);
-            }
+            for (int j = 0; j < VEC; ++j) r.g[p].e[j] = r.g[p].e[j] + r.s[p].e[j];
         }
+    }
+}
+
+// One tile = kThreads * VPT vectors; a thread owns vectors tile_base + p * kThreads + tid.
+// In the one partial tile (GUARD) out-of-range threads redo the last vector's loads and skip
+// the stores, so the instruction stream is the unguarded one.
+template <int OPT, int VEC, int VPT, int U, bool NT, bool GUARD>
+__device__ __forceinline__ void reduce_tile(const ReduceArgs& a, unsigned base) {
+    unsigned idx[VPT];
+    bool ok[VPT];
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+        unsigned i = base + p * kThreads + threadIdx.x;
+        ok[p] = !GUARD || i < a.n;
+        idx[p] = ok[p] ? i : a.n - 1;
+    }
+    TileRegs<VEC, VPT> r;
+    fold_tile<OPT, VEC, VPT, U, NT>(a, idx, r);
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+        if (!ok[p]) continue;
+        if (!a.last) {
+            store_result(a.step_out, idx[p], r.s[p], a.wt);
+            continue;
+        }
+        if (OPT != FA_OPT_NONE) {
+            store_result(a.v, idx[p], r.v[p], a.wt);
+            if (OPT != FA_OPT_AVGM) store_result(a.m, idx[p], r.m[p], a.wt);
+        }
+        if (a.step_out) store_result(a.step_out, idx[p], r.s[p], a.wt);
+        if (a.apply) store_result(a.g, idx[p], r.g[p], a.wt);
     }
 }
 
@@ -233,6 +267,108 @@ __global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
             reduce_tile<OPT, VEC, VPT, U, NT, false>(a, t * kTile);
         else
             reduce_tile<OPT, VEC, VPT, U, NT, true>(a, t * kTile);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent variant for large vectors: one 256-thread block per CU walks a contiguous range of
+// the parameter axis and parks each tile's results in LDS (every thread only ever touches its
+// own slots, so no barrier is needed); after kStashBytes of results it writes them out in one
+// burst of write-through stores.  HBM handles a few large write bursts far better than a
+// 16-KB write trickling out of every tile between the reads (measured on MI355X: the g
+// write-back of a K = 64 round costs 16 % of the kernel when it trickles, 6 % in bursts).
+
+constexpr int kStashVpt = 4;
+constexpr int kStashUnroll = 8;
+constexpr unsigned kStashTile = kThreads * kStashVpt;                 // vectors per tile
+constexpr unsigned kStashVecBytes = kStashTile * 16;                  // 16 KiB per result vector
+constexpr unsigned kStashBytes = 144 * 1024;                          // LDS budget of a block
+
+// What a launch writes back per tile.
+enum { kOutFinal = 0, kOutFinalStep = 1, kOutStepOnly = 2 };
+
+template <int OPT, int MODE>
+struct StashShape {
+    static constexpr int kVectors =
+        MODE == kOutStepOnly
+            ? 1
+            : 1 + (OPT != FA_OPT_NONE) + (OPT >= FA_OPT_ADAM) + (MODE == kOutFinalStep);
+    static constexpr int kTiles =
+        (kStashBytes / kStashVecBytes / kVectors) > 8 ? 8 : (kStashBytes / kStashVecBytes / kVectors);
+};
+
+__device__ __forceinline__ void burst_store(float* base, unsigned bytes, unsigned idx, const f4& v) {
+    // write-through (sc0 sc1) 128-bit store
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, static_cast<int>(bytes), 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, idx * 16u, 0, 17);
+}
+
+template <int OPT, int MODE>
+__global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceArgs a) {
+    constexpr int NV = StashShape<OPT, MODE>::kVectors;
+    constexpr int S = StashShape<OPT, MODE>::kTiles;
+    __shared__ f4 stash[S][NV][kStashVpt][kThreads];
+    // contiguous range of this block, in units of one wave-row (64 vectors)
+    const unsigned units = (a.n + 63u) / 64u;
+    const unsigned u0 = static_cast<unsigned>(static_cast<uint64_t>(units) * blockIdx.x / gridDim.x);
+    const unsigned u1 = static_cast<unsigned>(static_cast<uint64_t>(units) * (blockIdx.x + 1) / gridDim.x);
+    const unsigned r0 = u0 * 64u;
+    const unsigned r1 = (u1 * 64u < a.n) ? u1 * 64u : a.n;
+    if (r0 >= r1) return;
+    const unsigned nbytes = a.n * 16u;
+    float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (MODE == kOutStepOnly) {
+        dst[0] = a.step_out;
+    } else {
+        int c = 0;
+        dst[c++] = a.g;
+        if (OPT != FA_OPT_NONE) dst[c++] = a.v;
+        if (OPT >= FA_OPT_ADAM) dst[c++] = a.m;
+        if (MODE == kOutFinalStep) dst[c++] = a.step_out;
+    }
+    for (unsigned tb = r0; tb < r1; tb += S * kStashTile) {
+#pragma unroll 1
+        for (int j = 0; j < S; ++j) {
+            const unsigned base = tb + j * kStashTile;
+            if (base >= r1) break;
+            unsigned idx[kStashVpt];
+#pragma unroll
+            for (int p = 0; p < kStashVpt; ++p) {
+                unsigned i = base + p * kThreads + threadIdx.x;
+                idx[p] = i < r1 ? i : r1 - 1;
+            }
+            TileRegs<4, kStashVpt> r;
+            fold_tile<OPT, 4, kStashVpt, kStashUnroll, true>(a, idx, r);
+#pragma unroll
+            for (int p = 0; p < kStashVpt; ++p) {
+                int c = 0;
+                auto park = [&](const Pack<4>& v) {
+                    f4 t;
+                    t.x = v.e[0]; t.y = v.e[1]; t.z = v.e[2]; t.w = v.e[3];
+                    stash[j][c++][p][threadIdx.x] = t;
+                };
+                if (MODE == kOutStepOnly) {
+                    park(r.s[p]);
+                } else {
+                    park(r.g[p]);
+                    if (OPT != FA_OPT_NONE) park(r.v[p]);
+                    if (OPT >= FA_OPT_ADAM) park(r.m[p]);
+                    if (MODE == kOutFinalStep) park(r.s[p]);
+                }
+            }
+        }
+#pragma unroll 1
+        for (int j = 0; j < S; ++j) {
+            const unsigned base = tb + j * kStashTile;
+            if (base >= r1) break;
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int p = 0; p < kStashVpt; ++p) {
+                    const unsigned i = base + p * kThreads + threadIdx.x;
+                    if (i < r1) burst_store(dst[c], nbytes, i, stash[j][c][p][threadIdx.x]);
+                }
+        }
     }
 }
 
@@ -429,7 +565,7 @@ inline unsigned grid_for(size_t work_items) {
 }
 
 // Largest element count one launch indexes with 32-bit vector indices (a multiple of 4).
-constexpr size_t kSegment = size_t(1) << 30;
+constexpr size_t kSegment = size_t(1) << 29;
 
 // Launch shape of the 128-bit reduce kernel.  The defaults are the measured best on MI355X;
 // fa_tune() swaps them at run time so a benchmark can compare shapes inside one process.
@@ -438,8 +574,43 @@ struct Shape {
     int unroll;      // clients loaded ahead of the arithmetic: 4, 8 or 16
     int nt;          // non-temporal client loads
     int max_blocks;  // grid cap; tiles beyond it are walked grid-stride
+    int stash;       // the persistent LDS-stash kernel takes vectors with at least this many
+                     // tiles per CU (0: never, < 0: always); it pays off once every CU has
+                     // several tiles of its own
 };
-Shape g_shape = {4, 8, 1, kMaxBlocks};
+Shape g_shape = {4, 8, 1, kMaxBlocks, 4};
+int g_write_through = 1;   // fa_tune's nt field: bit 1 clear = plain result stores
+
+// Below this many clients per launch the persistent kernel's write bursts (which stall its
+// one-wave-per-SIMD loaders until the write-through stores retire) cost more than they save.
+constexpr int kStashMinClients = 48;
+
+int device_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+template <int OPT, int MODE>
+int launch_stash_m(const ReduceArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((reduce_stash_kernel<OPT, MODE>), dim3(device_cu_count()), dim3(kThreads), 0, st, a);
+    return launch_status();
+}
+
+template <int OPT>
+int launch_stash(const ReduceArgs& a, hipStream_t st) {
+    if (!a.last) return launch_stash_m<FA_OPT_NONE, kOutStepOnly>(a, st);
+    if (!a.apply) return launch_stash_m<FA_OPT_NONE, kOutStepOnly>(a, st);
+    if (a.step_out) return launch_stash_m<OPT, kOutFinalStep>(a, st);
+    return launch_stash_m<OPT, kOutFinal>(a, st);
+}
 
 template <int OPT, int VEC, int VPT, int U, bool NT>
 int launch_reduce_s(const ReduceArgs& a, hipStream_t st) {
@@ -468,6 +639,10 @@ int launch_reduce_u(const ReduceArgs& a, hipStream_t st) {
 template <int OPT, int VEC>
 int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
     if (VEC == 1) return launch_reduce_s<OPT, 1, 1, 8, true>(a, st);
+    if (g_shape.stash < 0 ||
+        (g_shape.stash > 0 && a.K >= kStashMinClients &&
+         a.n >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile))
+        return launch_stash<OPT>(a, st);
     switch (g_shape.vpt) {
         case 1: return launch_reduce_u<OPT, 1>(a, st);
         case 4: return launch_reduce_u<OPT, 4>(a, st);
@@ -526,6 +701,7 @@ int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStrea
         a.step_in = (ch == 0) ? nullptr : carry + off;
         a.step_out = a.last ? (c.step_out ? c.step_out + off : nullptr) : carry + off;
         a.h = c.h;
+        a.wt = g_write_through;
         a.n = static_cast<unsigned>(vec ? len / 4 : len);
         int rc = vec ? launch_reduce<4>(c.opt, a, st) : launch_reduce<1>(c.opt, a, st);
         if (rc != FA_OK) return rc;
@@ -709,13 +885,15 @@ int fa_version(void) { return 100; }
 
 int fa_kchunk(void) { return FA_KCHUNK; }
 
-int fa_tune(int vpt, int unroll, int nt, int max_blocks) {
+int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash) {
     if (vpt != 1 && vpt != 2 && vpt != 4) return FA_ERR_INVALID;
     if (unroll != 4 && unroll != 8 && unroll != 16) return FA_ERR_INVALID;
     g_shape.vpt = vpt;
     g_shape.unroll = unroll;
-    g_shape.nt = nt ? 1 : 0;
+    g_shape.nt = (nt & 1) ? 1 : 0;
+    g_write_through = (nt & 2) ? 0 : 1;
     g_shape.max_blocks = max_blocks > 0 ? max_blocks : kMaxBlocks;
+    g_shape.stash = stash;
     return FA_OK;
 }
 

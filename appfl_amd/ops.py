@@ -57,8 +57,8 @@ def kchunk() -> int:
     return N.load().fa_kchunk()
 
 
-def tune(vpt: int = 4, unroll: int = 8, nt: int = 1, max_blocks: int = 0) -> None:
-    N.check(N.load().fa_tune(vpt, unroll, nt, max_blocks), "fa_tune")
+def tune(vpt: int = 4, unroll: int = 8, nt: int = 1, max_blocks: int = 0, stash: int = 4) -> None:
+    N.check(N.load().fa_tune(vpt, unroll, nt, max_blocks, stash), "fa_tune")
 
 
 def reduce_opt(x: Sequence[torch.Tensor], w: Sequence[float], g: torch.Tensor,

@@ -58,11 +58,13 @@ const char* fa_error_string(int code);
 int fa_kchunk(void);
 /*
  * Benchmark hook (no counterpart in the reference): selects the launch shape of the 128-bit
- * reduce kernel -- vectors per thread (1|2|4), clients loaded ahead (4|8|16), non-temporal
- * client loads (0|1), grid cap (<= 0: default).  Results do not depend on it.  Process-wide;
- * not synchronised with concurrent calls.
+ * reduce kernel -- vectors per thread (1|2|4), clients loaded ahead (4|8|16), nt (bit 0:
+ * non-temporal client loads, bit 1: plain instead of write-through result stores), grid cap (<= 0: default) of the tile-per-block kernel, and from how many
+ * 16-KiB tiles per CU on a vector takes the persistent kernel that parks results in LDS and
+ * writes them in bursts (stash: 0 never, < 0 always, default 4).  Results do not depend on it.
+ * Process-wide; not synchronised with concurrent calls.
  */
-int fa_tune(int vpt, int unroll, int nt, int max_blocks);
+int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);
 
 /*
  * Weighted FedAvg step fused with the apply and the server-optimizer epilogue.

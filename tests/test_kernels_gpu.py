@@ -263,10 +263,72 @@ def test_every_launch_shape_gives_the_same_bits():
         for vpt in (1, 2, 4):
             for unroll in (4, 8, 16):
                 for nt in (0, 1):
-                    ops.tune(vpt, unroll, nt, 64)
+                    ops.tune(vpt, unroll, nt, 64, 0)
                     g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, np.float32(1e-6)))
                     ops.reduce_opt(dx, w, g, m, v, "adam", **HP)
                     assert_bits(g, g_ref, f"g vpt={vpt} u={unroll} nt={nt}")
                     assert_bits(v, v_ref, f"v vpt={vpt} u={unroll} nt={nt}")
     finally:
         ops.tune()
+
+
+@pytest.mark.parametrize("opt,hp", [("none", {}), ("avgm", HP), ("adam", HP), ("yogi", HP_YOGI), ("adagrad", HP)])
+@pytest.mark.parametrize("n", [7, 1027, 300007, 4500003])
+def test_persistent_stash_kernel_matches_oracle(opt, hp, n):
+    """The persistent LDS-stash kernel forced on (also for vectors far smaller than its grid, so
+    most blocks own an empty or partial range) and at its natural size: same bits as the oracle
+    for the final state, the optional step output and the step-only mode."""
+    from appfl_amd import ops
+    K = 5 if n > 1000000 else 11
+    code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI,
+            "adagrad": O.OPT_ADAGRAD}[opt]
+    base, xs = make_clients(n, K)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v_ref = np.full_like(base, np.float32(0.0 if opt in ("none", "avgm") else hp["tau"] ** 2))
+    step_ref = np.empty_like(base)
+    pre_ref = np.empty_like(base)
+    O.reduce_step(xs, w, base, pre_ref)
+    O.reduce_opt(xs, w, g_ref, m_ref, v_ref, code, step_out=step_ref, **hp)
+    dx = [dev(x) for x in xs]
+    try:
+        ops.tune(stash=-1)
+        for with_step in (False, True):
+            g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, v_ref.flat[0] * 0 + (
+                np.float32(0.0 if opt in ("none", "avgm") else hp["tau"] ** 2))))
+            step = torch.full((n,), 7.0, device="cuda") if with_step else None
+            ops.reduce_opt(dx, w, g, m if opt not in ("none", "avgm") else None,
+                           v if opt != "none" else None, opt, step_out=step, **hp)
+            assert_bits(g, g_ref, f"g step_out={with_step}")
+            if opt != "none":
+                assert_bits(v, v_ref, "v")
+            if opt not in ("none", "avgm"):
+                assert_bits(m, m_ref, "m")
+            if with_step:
+                assert_bits(step, step_ref, "step")
+        g = dev(base)
+        pre = torch.empty_like(g)
+        ops.reduce_step(dx, w, g, pre)
+        assert_bits(pre, pre_ref, "step-only")
+        assert_bits(g, base, "g untouched")
+    finally:
+        ops.tune()
+
+
+def test_persistent_stash_kernel_with_client_chunks():
+    """K > FA_KCHUNK through the persistent kernel: the carry pass parks the partial step."""
+    from appfl_amd import ops
+    n, K = 70003, ops.kchunk() + 5
+    base, xs = make_clients(n, K, spike=False)
+    w = [1.0 / K] * K
+    g_ref, m_ref, v_ref = base.copy(), np.zeros_like(base), np.full_like(base, np.float32(1e-6))
+    O.reduce_opt(xs, w, g_ref, m_ref, v_ref, O.OPT_ADAM, **HP)
+    g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, np.float32(1e-6)))
+    try:
+        ops.tune(stash=-1)
+        ops.reduce_opt([dev(x) for x in xs], w, g, m, v, "adam", step_ws=torch.empty_like(g), **HP)
+    finally:
+        ops.tune()
+    assert_bits(g, g_ref, "g")
+    assert_bits(m, m_ref, "m")
+    assert_bits(v, v_ref, "v")

@@ -46,28 +46,28 @@ __global__ __launch_bounds__(256) void rk(const float* __restrict__ p, size_t ro
 }
 
 // Results parked in LDS and written in bursts of STASH tiles (one 256-thread block per CU, persistent).
-template <int STASH>
-__global__ __launch_bounds__(256) void rk_stash(const float* __restrict__ p, size_t row, int K, unsigned n4, const float* __restrict__ gp, float* __restrict__ gout, float w) {
-    constexpr int U = 8, VPT = 4;
-    __shared__ f4 stash[STASH][VPT][256];
-    unsigned tiles = n4 / (256 * VPT);
+template <int STASH, int SAUX = 0, bool BARRIER = false, int TH = 256, int U = 8, int VPT = 4>
+__global__ __launch_bounds__(TH) void rk_stash(const float* __restrict__ p, size_t row, int K, unsigned n4, const float* __restrict__ gp, float* __restrict__ gout, float w, unsigned* counter = nullptr) {
+    __shared__ f4 stash[STASH][VPT][TH];
+    unsigned tiles = n4 / (TH * VPT);
     unsigned per = (tiles + gridDim.x - 1) / gridDim.x;        // contiguous tile range per block
     unsigned t0 = blockIdx.x * per, t1 = min(tiles, t0 + per);
     __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gp, 0, (int)(n4 * 16), 0x00020000);
     __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)gout, 0, (int)(n4 * 16), 0x00020000);
-    for (unsigned tb = t0; tb < t1; tb += STASH) {
-        unsigned cnt = min((unsigned)STASH, t1 - tb);
+    unsigned phase = 0;
+    for (unsigned tb = t0; tb < t0 + per; tb += STASH) {
+        unsigned cnt = tb < t1 ? min((unsigned)STASH, t1 - tb) : 0;
         for (unsigned j = 0; j < cnt; ++j) {
-            unsigned base = ((tb + j) * 256 * VPT + threadIdx.x) * 16;
+            unsigned base = ((tb + j) * TH * VPT + threadIdx.x) * 16;
             f4 acc[VPT], g[VPT];
-            for (int q = 0; q < VPT; ++q) { acc[q] = f4{0, 0, 0, 0}; g[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rg, base + q * 4096, 0, 0)); }
+            for (int q = 0; q < VPT; ++q) { acc[q] = f4{0, 0, 0, 0}; g[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rg, base + q * (TH * 16), 0, 0)); }
             for (int k = 0; k + U <= K; k += U) {
                 f4 x[U][VPT];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p + (size_t)(k + u) * row), 0, (int)(n4 * 16), 0x00020000);
 #pragma unroll
-                    for (int q = 0; q < VPT; ++q) x[u][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rx, base + q * 4096, 0, 2));
+                    for (int q = 0; q < VPT; ++q) x[u][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rx, base + q * (TH * 16), 0, 2));
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -76,9 +76,71 @@ __global__ __launch_bounds__(256) void rk_stash(const float* __restrict__ p, siz
             }
             for (int q = 0; q < VPT; ++q) stash[j][q][threadIdx.x] = g[q] + acc[q];
         }
+        if (BARRIER) {
+            ++phase;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * gridDim.x && ++spins < 4000000u) __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
         for (unsigned j = 0; j < cnt; ++j) {
-            unsigned base = ((tb + j) * 256 * VPT + threadIdx.x) * 16;
-            for (int q = 0; q < VPT; ++q) __builtin_amdgcn_raw_buffer_store_b128(as_u4(stash[j][q][threadIdx.x]), ro, base + q * 4096, 0, 0);
+            unsigned base = ((tb + j) * TH * VPT + threadIdx.x) * 16;
+            for (int q = 0; q < VPT; ++q) __builtin_amdgcn_raw_buffer_store_b128(as_u4(stash[j][q][threadIdx.x]), ro, base + q * (TH * 16), 0, SAUX);
+        }
+    }
+}
+
+// Stash kernel with a software-pipelined client loop: two register sets of U clients, the next
+// set's loads are issued before the current set is consumed.
+template <int STASH, int SAUX, int U, int VPT>
+__global__ __launch_bounds__(256) void rk_pipe(const float* __restrict__ p, size_t row, int K, unsigned n4, const float* __restrict__ gp, float* __restrict__ gout, float w) {
+    constexpr int TH = 256;
+    __shared__ f4 stash[STASH][VPT][TH];
+    unsigned tiles = n4 / (TH * VPT);
+    unsigned per = (tiles + gridDim.x - 1) / gridDim.x;
+    unsigned t0 = blockIdx.x * per, t1 = min(tiles, t0 + per);
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gp, 0, (int)(n4 * 16), 0x00020000);
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)gout, 0, (int)(n4 * 16), 0x00020000);
+    for (unsigned tb = t0; tb < t1; tb += STASH) {
+        unsigned cnt = min((unsigned)STASH, t1 - tb);
+        for (unsigned j = 0; j < cnt; ++j) {
+            unsigned base = ((tb + j) * TH * VPT + threadIdx.x) * 16;
+            f4 acc[VPT], g[VPT];
+            for (int q = 0; q < VPT; ++q) { acc[q] = f4{0, 0, 0, 0}; g[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rg, base + q * (TH * 16), 0, 0)); }
+            f4 xa[U][VPT], xb[U][VPT];
+            auto issue = [&](f4 (&x)[U][VPT], int k) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p + (size_t)(k + u) * row), 0, (int)(n4 * 16), 0x00020000);
+#pragma unroll
+                    for (int q = 0; q < VPT; ++q) x[u][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rx, base + q * (TH * 16), 0, 2));
+                }
+            };
+            auto consume = [&](f4 (&x)[U][VPT]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int q = 0; q < VPT; ++q) acc[q] = acc[q] + (x[u][q] - g[q]) * w;
+            };
+            issue(xa, 0);
+            int k = 0;
+            for (; k + 2 * U < K; k += 2 * U) {   // assumes K % (2U) == 0
+                issue(xb, k + U);
+                consume(xa);
+                issue(xa, k + 2 * U);
+                consume(xb);
+            }
+            issue(xb, k + U);
+            consume(xa);
+            consume(xb);
+            for (int q = 0; q < VPT; ++q) stash[j][q][threadIdx.x] = g[q] + acc[q];
+        }
+        for (unsigned j = 0; j < cnt; ++j) {
+            unsigned base = ((tb + j) * TH * VPT + threadIdx.x) * 16;
+            for (int q = 0; q < VPT; ++q) __builtin_amdgcn_raw_buffer_store_b128(as_u4(stash[j][q][threadIdx.x]), ro, base + q * (TH * 16), 0, SAUX);
         }
     }
 }
@@ -112,16 +174,25 @@ void run(const char* name, int grid = 0) {
     CK(hipGetLastError());
     printf("%-44s %.3f ms %6.0f GB/s client\n", name, ms, n * 4 / ms / 1e6);
 }
-template <int STASH>
+unsigned* counter;
+template <int STASH, int SAUX = 0, bool BARRIER = false, int TH = 256, int U = 8, int VPT = 4>
 void run_stash(const char* name, int grid) {
     unsigned r4 = row / 4;
-    float ms = timeit([&] { rk_stash<STASH><<<grid, 256>>>(p, row, K, r4, q, q + row, 0.015625f); });
+    float ms = timeit([&] { CK(hipMemsetAsync(counter, 0, 4)); rk_stash<STASH, SAUX, BARRIER, TH, U, VPT><<<grid, TH>>>(p, row, K, r4, q, q + row, 0.015625f, counter); });
+    CK(hipGetLastError());
+    printf("%-44s %.3f ms %6.0f GB/s client\n", name, ms, n * 4 / ms / 1e6);
+}
+
+template <int STASH, int SAUX, int U, int VPT>
+void run_pipe(const char* name, int grid) {
+    unsigned r4 = row / 4;
+    float ms = timeit([&] { rk_pipe<STASH, SAUX, U, VPT><<<grid, 256>>>(p, row, K, r4, q, q + row, 0.015625f); });
     CK(hipGetLastError());
     printf("%-44s %.3f ms %6.0f GB/s client\n", name, ms, n * 4 / ms / 1e6);
 }
 
 int main() {
-    CK(hipMalloc(&p, n * 4)); CK(hipMalloc(&q, row * 8));
+    CK(hipMalloc(&p, n * 4)); CK(hipMalloc(&q, row * 8)); CK(hipMalloc(&counter, 256));
     fill_rand<<<4096, 256>>>((unsigned*)p, n); fill_rand<<<4096, 256>>>((unsigned*)q, row * 2); CK(hipDeviceSynchronize());
     run<2, 0, 1>("load nt, store plain");
     run<2, 0, 1000000>("load nt, no store");
@@ -146,5 +217,22 @@ int main() {
     run_stash<4>("stash 4 tiles (64KB LDS), grid 512", 512);
     run_stash<8>("stash 8 tiles (128KB LDS), grid 256", 256);
     run_stash<2>("stash 2 tiles (32KB LDS), grid 512", 512);
+    run_stash<8, 17>("stash 8 tiles, sc0 sc1 stores, grid 256", 256);
+    run_stash<8, 0, true>("stash 8 tiles, chip barrier before writes, grid 256", 256);
+    run_stash<8, 17, true>("stash 8, barrier, sc0 sc1, grid 256", 256);
+    run_stash<4, 0, true>("stash 4 tiles, barrier, grid 256", 256);
+    run_stash<9>("stash 9 tiles (144KB), grid 256", 256);
+    run_stash<9, 17>("stash 9 tiles (144KB), sc0sc1, grid 256", 256);
+    run_stash<4, 17, false, 512>("512 thr, stash 4 x 32KB, sc0sc1, grid 256", 256);
+    run_stash<4, 17, false, 512, 4>("512 thr, U=4, stash 4 x 32KB, sc0sc1", 256);
+    run_stash<8, 17, false, 512, 8, 2>("512 thr, vpt 2, stash 8 x 16KB, sc0sc1", 256);
+    run_stash<8, 17, false, 512, 4, 2>("512 thr, vpt 2, U=4, stash 8 x 16KB, sc0sc1", 256);
+    run_stash<8, 17, false, 1024, 8, 1>("1024 thr, vpt 1, stash 8 x 16KB, sc0sc1", 256);
+    run_stash<4, 17, false, 1024, 4, 2>("1024 thr, vpt 2 U=4, stash 4 x 32KB, sc0sc1", 256);
+    run_stash<8, 17, false, 256, 16, 2>("256 thr, vpt 2 U=16, stash 8 x 8KB, sc0sc1", 256);
+    run_pipe<8, 17, 4, 4>("pipelined 2x(U=4) vpt 4, stash 8, sc0sc1", 256);
+    run_pipe<8, 17, 8, 2>("pipelined 2x(U=8) vpt 2, stash 8(x8KB), sc0sc1", 256);
+    run_pipe<8, 17, 2, 4>("pipelined 2x(U=2) vpt 4, stash 8, sc0sc1", 256);
+    run_pipe<4, 17, 4, 4>("pipelined 2x(U=4) vpt 4, stash 4, grid 512", 512);
     return 0;
 }
