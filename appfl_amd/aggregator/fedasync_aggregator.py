@@ -20,7 +20,7 @@ import torch
 
 from .. import ops
 from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout
-from ..staging import ClientSlab
+from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_require,
                               resolve_device)
 
@@ -68,6 +68,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         self._flats: Optional[Dict[str, torch.Tensor]] = None
         self._slab: Optional[ClientSlab] = None
         self._step_flats: Optional[Dict[str, torch.Tensor]] = None
+        self._dl = HostDownloader()
         self._init_lock()
 
     @property
@@ -93,7 +94,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         lay = self._layout
         host = {}
         for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
-            host[key] = self._flats[key][:n].cpu() if n else torch.empty(0, dtype=self._flats[key].dtype)
+            host[key] = self._dl.fetch(self._flats[key], n)
         return lay.views(host)
 
     def _init_global_state(self, local_model):

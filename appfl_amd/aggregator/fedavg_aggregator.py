@@ -28,7 +28,7 @@ import torch
 
 from .. import ops
 from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout, split_names_by_size
-from ..staging import ClientSlab
+from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_require,
                               resolve_device)
 
@@ -40,11 +40,13 @@ class _ChunkState:
         self.layout, self.flats, self.slab = layout, flats, slab
 
 
-def _download_flats(lay: Layout, flats: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+def _download_flats(lay: Layout, flats: Dict[str, torch.Tensor],
+                    dl: Optional[HostDownloader] = None) -> Dict[str, torch.Tensor]:
     """Fresh CPU copy of flat state vectors: one D2H copy per dtype, entries are views of it."""
+    dl = dl or HostDownloader()
     host = {}
     for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
-        host[key] = flats[key][:n].cpu() if n else torch.empty(0, dtype=flats[key].dtype)
+        host[key] = dl.fetch(flats[key], n)
     return lay.views(host)
 
 
@@ -87,6 +89,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._step_flat: Optional[torch.Tensor] = None
         self._staged_for = None
         self._chunks: Dict[tuple, "_ChunkState"] = {}    # streamed aggregation, one per key set
+        self._dl = HostDownloader()
         self._init_lock()
 
     # -- attributes the reference exposes -------------------------------------------------------
@@ -155,7 +158,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             if self._layout is None and self._chunks:
                 merged = {}
                 for st in self._chunks.values():
-                    merged.update(_download_flats(st.layout, st.flats))
+                    merged.update(_download_flats(st.layout, st.flats, self._dl))
                 return merged
             if self._layout is None:
                 if self.model is None:
@@ -186,7 +189,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         lay = self._layout
         if names is not None:
             return {n: lay.view(self._flats, n).cpu() for n in names if n in lay.by_name}
-        return _download_flats(lay, self._flats)
+        return _download_flats(lay, self._flats, self._dl)
 
     def _client_weights(self, local_models) -> list:
         """fedavg_aggregator.py:343-358."""
@@ -341,7 +344,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 ops.mean(rows(lay.seg_byte[MEAN_I64]), st.flats["i64"], n=lay.count[MEAN_I64])
             if lay.count[MEAN_I32]:
                 ops.mean(rows(lay.seg_byte[MEAN_I32]), st.flats["i32"], n=lay.count[MEAN_I32])
-            out = _download_flats(lay, st.flats)
+            out = _download_flats(lay, st.flats, self._dl)
             self._sync_model(self.model, out)        # partial update (:447-452)
             return {k: out[k] for k in chunk_keys if k in out}
 

@@ -126,3 +126,29 @@ class ClientSlab:
         """Make the compute stream wait for every upload of this round."""
         if self.last_copy is not None:
             torch.cuda.current_stream(self.device).wait_event(self.last_copy)
+
+
+class HostDownloader:
+    """Device -> host copies of flat state vectors into FRESH pageable tensors: one pinned D2H
+    transfer (PCIe rate) into a reusable pinned buffer, then a multi-threaded memcpy that also
+    spreads the first-touch page faults of the new tensor over the copy threads."""
+
+    def __init__(self):
+        self._pinned: Dict[torch.dtype, torch.Tensor] = {}
+
+    def fetch(self, flat: torch.Tensor, n: int) -> torch.Tensor:
+        if n == 0:
+            return torch.empty(0, dtype=flat.dtype)
+        buf = self._pinned.get(flat.dtype)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(n, dtype=flat.dtype, pin_memory=True)
+            self._pinned[flat.dtype] = buf
+        buf[:n].copy_(flat[:n], non_blocking=True)
+        torch.cuda.current_stream(flat.device).synchronize()
+        out = torch.empty(n, dtype=flat.dtype)
+        nbytes = n * flat.element_size()
+        rc = N.load().fa_pack_host(
+            C.c_void_p(out.data_ptr()), (C.c_void_p * 1)(buf.data_ptr()), (C.c_size_t * 1)(0),
+            (C.c_size_t * 1)(nbytes), 1, PACK_THREADS)
+        N.check(rc, "fa_pack_host")
+        return out
