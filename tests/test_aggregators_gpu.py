@@ -127,3 +127,29 @@ def test_chunked_get_parameters():
     assert sorted(seen) == sorted(whole)
     for k in whole:
         assert torch.equal(seen[k], whole[k])
+
+
+def test_config1_mnist_cnn_serial_harness_matches_oracle():
+    """BASELINE config #1 (MNIST CNN, FedAvg, 2 clients, serial) through the harness: the HIP
+    aggregator and the oracle agree bit for bit over three rounds."""
+    import appfl_amd.aggregator as A
+    from appfl_amd import workloads as W
+    from appfl_amd.harness import SerialSyncHarness
+    spec = {n: (shape, "f32") for n, shape, _, _ in W.mnist_cnn()}
+    cfg = {"client_weights_mode": "sample_size"}
+    hs = [SerialSyncHarness(A.FedAvgAggregator(None, cfg, None), 2),
+          SerialSyncHarness(OA.OracleFedAvg(None, cfg, None), 2)]
+    for h in hs:
+        h.set_sample_size(0, 100)
+        h.set_sample_size(1, 300)
+    for r in range(3):
+        outs = []
+        for h in hs:
+            f0 = h.global_update(0, S.make_state(spec, seed=10 * r + 1))
+            f1 = h.global_update(1, S.make_state(spec, seed=10 * r + 2))
+            assert f0.result() is f1.result()
+            outs.append(f0.result())
+        for k in outs[1]:
+            got = outs[0][k].numpy() if isinstance(outs[0][k], torch.Tensor) else outs[0][k]
+            assert golden_util.same_bits(got, outs[1][k]), (r, k)
+    assert hs[0].get_num_global_epochs() == 3

@@ -1,0 +1,119 @@
+"""Host-side logic that needs no GPU: the C ABI surface, layout / row packing, chunking rule,
+workload tables, the serial harness (BASELINE config #1 plumbing) driven by the oracle."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import scenarios as S
+from appfl_amd import _native as N
+from appfl_amd import layout as L
+from appfl_amd import workloads as W
+from oracle import aggregators as OA
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "appfl_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(fa_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 25
+    lib = N.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    assert lib.fa_version() >= 100 and lib.fa_kchunk() == 128
+    assert lib.fa_error_string(-2) == b"buffer not aligned to its element size"
+
+
+def test_argument_checks_without_touching_the_gpu():
+    lib = N.load()
+    assert lib.fa_reduce_opt(None, None, 0, None, None, None, 0, 0, 0, 0, 0, 0, None, None, None) == -1
+    assert lib.fa_tune(3, 8, 1, 0, 4) == -1 and lib.fa_tune(4, 8, 1, 0, 4) == 0
+    assert lib.fa_pack_host(None, None, None, None, 0, 1) == -1
+
+
+def test_pack_host_matches_numpy():
+    rng = np.random.default_rng(0)
+    sizes = [5, 0, 4099, 3 * 1024 * 1024 + 7, 17]
+    srcs = [rng.integers(0, 255, s, dtype=np.uint8) for s in sizes]
+    offs, pos = [], 3
+    for s in sizes:
+        offs.append(pos)
+        pos += s + 5
+    for threads in (1, 4, 7):
+        dst = np.zeros(pos, np.uint8)
+        T = len(sizes)
+        rc = N.load().fa_pack_host(
+            C.c_void_p(dst.ctypes.data), (C.c_void_p * T)(*[a.ctypes.data if a.size else None for a in srcs]),
+            (C.c_size_t * T)(*offs), (C.c_size_t * T)(*sizes), T, threads)
+        assert rc == 0
+        want = np.zeros(pos, np.uint8)
+        for a, o in zip(srcs, offs):
+            want[o:o + a.size] = a
+        assert np.array_equal(dst, want), threads
+
+
+def test_layout_classes_offsets_and_rows():
+    model = S.ToyModel()
+    state = model.state_dict()
+    named = {n for n, _ in model.named_parameters()}
+    lay = L.Layout([(n, tuple(t.shape), t.dtype) for n, t in state.items()], named)
+    assert lay.count[L.STEP] == 108 + 4 + 4 + 640 + 10 and lay.count[L.MEAN_F32] == 8
+    assert lay.count[L.MEAN_I64] == 1 and lay.count[L.MEAN_I32] == 0
+    assert lay.names == list(state)
+    assert lay.seg_byte[L.MEAN_I64] % 16 == 0 and lay.row_bytes % 256 == 0
+    spans = sorted((e.byte_offset, e.byte_offset + e.numel * e.dtype.itemsize) for e in lay.entries)
+    for (a, b), (c, d) in zip(spans, spans[1:]):
+        assert b <= c
+    flats = {"f32": torch.arange(lay.n_f32, dtype=torch.float32), "i64": torch.tensor([5]),
+             "i32": torch.zeros(1, dtype=torch.int32)}
+    v = lay.views(flats)
+    assert v["bn.num_batches_tracked"].shape == () and int(v["bn.num_batches_tracked"]) == 5
+    assert v["bn.running_mean"].data_ptr() == flats["f32"][lay.count[L.STEP]:].data_ptr()
+    nomodel = L.Layout([(n, tuple(t.shape), t.dtype) for n, t in state.items()], None)
+    assert nomodel.count[L.MEAN_F32] == 0
+    with pytest.raises(NotImplementedError):
+        L.Layout([("h", (3,), torch.float16)], None)
+
+
+def test_chunking_rule():
+    sizes = {"b": 400, "a": 300, "huge": 5000, "c": 700, "d": 100}
+    assert L.split_names_by_size(sizes, 1000) == [["a", "b"], ["c", "d"], ["huge"]]
+    assert S.chunk_keys_by_size(S.TOY, 600) == [
+        ["bn.bias", "bn.num_batches_tracked", "bn.running_mean", "bn.running_var", "bn.weight",
+         "conv.weight", "fc.bias"], ["fc.weight"]]
+
+
+def test_workload_tables_have_the_published_parameter_counts():
+    assert W.numel(W.resnet(18), True) == 11689512 and len(W.resnet(18)) == 122
+    assert W.numel(W.resnet(50), True) == 25557032 and len(W.resnet(50)) == 320
+    assert W.numel(W.vit_b_16()) == 86567656 and len(W.vit_b_16()) == 152
+    assert W.numel(W.mnist_cnn()) == 582026 and len(W.mnist_cnn()) == 8
+
+
+def test_serial_harness_runs_config1_plumbing_with_the_oracle():
+    """MNIST CNN, FedAvg, 2 clients, serial simulation: Future semantics and the round result."""
+    from appfl_amd.harness import SerialSyncHarness
+    rows = W.mnist_cnn()
+    spec = {n: (shape, "f32") for n, shape, _, _ in rows}
+    h = SerialSyncHarness(OA.OracleFedAvg(None, {"client_weights_mode": "sample_size"}, None), 2)
+    h.set_sample_size("c0", 100)
+    h.set_sample_size("c1", 300)
+    with pytest.raises(ValueError):
+        h.get_parameters()
+    a, b = S.make_state(spec, seed=1), S.make_state(spec, seed=2)
+    f0 = h.global_update("c0", a, blocking=False, val_accuracy=0.1)
+    assert not f0.done() and h.get_num_global_epochs() == 0
+    f1 = h.global_update("c1", b, blocking=False, val_accuracy=0.2)
+    assert f0.done() and f1.done() and f0.result() is f1.result()
+    assert h.get_num_global_epochs() == 1
+    out = f0.result()
+    # first round without a model: g = a, step = 0.25 (a - a) + 0.75 (b - a)
+    want = a["fc2.bias"].numpy() + (np.float32(0.75) * (b["fc2.bias"].numpy() - a["fc2.bias"].numpy())
+                                    + np.float32(0.25) * np.float32(0.0))
+    assert np.allclose(out["fc2.bias"], want, rtol=0, atol=1e-7)
