@@ -12,7 +12,8 @@ import threading
 from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libappfl_amd.so")
+# APPFL_AMD_LIB selects another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("APPFL_AMD_LIB") or os.path.join(_HERE, "lib", "libappfl_amd.so")
 
 FA_OK = 0
 FA_OPT_NONE, FA_OPT_AVGM, FA_OPT_ADAM, FA_OPT_YOGI, FA_OPT_ADAGRAD = range(5)

@@ -303,11 +303,21 @@ __device__ __forceinline__ void burst_store(float* base, unsigned bytes, unsigne
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, idx * 16u, 0, 17);
 }
 
+// The client loop of the persistent kernel is software-pipelined ACROSS tiles: two register
+// sets of kStashUnroll clients x kStashVpt vectors are in flight; after a set is consumed the
+// loads of the set two steps ahead are issued -- which may belong to the next tile, whose g / m
+// / v are fetched with its first set.  The optimizer epilogue, the LDS parking and the burst
+// stores of a tile therefore run while the next tile's client bytes are already on their way
+// (with one wave per SIMD nothing else would hide them), and at one wave per SIMD the kernel
+// may spend up to 512 VGPRs per lane on this.
 template <int OPT, int MODE>
 __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceArgs a) {
     constexpr int NV = StashShape<OPT, MODE>::kVectors;
     constexpr int S = StashShape<OPT, MODE>::kTiles;
-    __shared__ f4 stash[S][NV][kStashVpt][kThreads];
+    constexpr int U = kStashUnroll, VPT = kStashVpt;
+    constexpr bool kHasV = MODE != kOutStepOnly && OPT != FA_OPT_NONE;
+    constexpr bool kHasM = MODE != kOutStepOnly && OPT >= FA_OPT_ADAM;
+    __shared__ f4 stash[S][NV][VPT][kThreads];
     // contiguous range of this block, in units of one wave-row (64 vectors)
     const unsigned units = (a.n + 63u) / 64u;
     const unsigned u0 = static_cast<unsigned>(static_cast<uint64_t>(units) * blockIdx.x / gridDim.x);
@@ -315,60 +325,148 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
     const unsigned r0 = u0 * 64u;
     const unsigned r1 = (u1 * 64u < a.n) ? u1 * 64u : a.n;
     if (r0 >= r1) return;
+    const unsigned ntiles = (r1 - r0 + kStashTile - 1) / kStashTile;
+    const int nb = (a.K + U - 1) / U;   // client sets per tile (the host guarantees nb >= 2)
     const unsigned nbytes = a.n * 16u;
+    const float* gsrc = a.apply ? a.g : a.g_ro;
     float* dst[4] = {nullptr, nullptr, nullptr, nullptr};
     if (MODE == kOutStepOnly) {
         dst[0] = a.step_out;
     } else {
         int c = 0;
         dst[c++] = a.g;
-        if (OPT != FA_OPT_NONE) dst[c++] = a.v;
-        if (OPT >= FA_OPT_ADAM) dst[c++] = a.m;
+        if (kHasV) dst[c++] = a.v;
+        if (kHasM) dst[c++] = a.m;
         if (MODE == kOutFinalStep) dst[c++] = a.step_out;
     }
-    for (unsigned tb = r0; tb < r1; tb += S * kStashTile) {
-#pragma unroll 1
-        for (int j = 0; j < S; ++j) {
-            const unsigned base = tb + j * kStashTile;
-            if (base >= r1) break;
-            unsigned idx[kStashVpt];
+
+    Pack<4> xa[U][VPT], xb[U][VPT];
+    Pack<4> g_cur[VPT], s_cur[VPT], m_cur[VPT], v_cur[VPT];
+    Pack<4> g_nxt[VPT], s_nxt[VPT], m_nxt[VPT], v_nxt[VPT];
+    unsigned it = 0, ct = 0;   // tile being issued / consumed
+    int ib = 0, cb = 0;        // client set within that tile
+
+    auto vec_index = [&](unsigned tile, int p) -> unsigned {
+        const unsigned i = r0 + tile * kStashTile + p * kThreads + threadIdx.x;
+        return i < r1 ? i : r1 - 1;   // threads past the range redo the last vector, never store
+    };
+    auto issue = [&](Pack<4> (&x)[U][VPT]) {
+        if (it >= ntiles) return;
+        unsigned idx[VPT];
 #pragma unroll
-            for (int p = 0; p < kStashVpt; ++p) {
-                unsigned i = base + p * kThreads + threadIdx.x;
-                idx[p] = i < r1 ? i : r1 - 1;
+        for (int p = 0; p < VPT; ++p) idx[p] = vec_index(it, p);
+        if (ib == 0) {
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) {
+                g_nxt[p] = load_state<4>(gsrc, idx[p]);
+                if (a.step_in) s_nxt[p] = load_state<4>(a.step_in, idx[p]);
+                if (kHasV && a.last) v_nxt[p] = load_state<4>(a.v, idx[p]);
+                if (kHasM && a.last) m_nxt[p] = load_state<4>(a.m, idx[p]);
             }
-            TileRegs<4, kStashVpt> r;
-            fold_tile<OPT, 4, kStashVpt, kStashUnroll, true>(a, idx, r);
+        }
+        const int k0 = ib * U;
 #pragma unroll
-            for (int p = 0; p < kStashVpt; ++p) {
-                int c = 0;
-                auto park = [&](const Pack<4>& v) {
-                    f4 t;
-                    t.x = v.e[0]; t.y = v.e[1]; t.z = v.e[2]; t.w = v.e[3];
-                    stash[j][c++][p][threadIdx.x] = t;
-                };
-                if (MODE == kOutStepOnly) {
-                    park(r.s[p]);
+        for (int u = 0; u < U; ++u) {
+            const int k = (k0 + u < a.K) ? k0 + u : a.K - 1;
+            const float* xp = a.x[k];
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) x[u][p] = load_stream<4, true>(xp, idx[p]);
+        }
+        if (++ib == nb) {
+            ib = 0;
+            ++it;
+        }
+    };
+    auto finish_tile = [&]() {
+        const int j = static_cast<int>(ct % S);
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            if (a.last && MODE != kOutStepOnly) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (OPT != FA_OPT_NONE) {
+                        float mj = kHasM ? m_cur[p].e[e] : 0.0f;
+                        s_cur[p].e[e] = optimizer_step<OPT>(s_cur[p].e[e], mj, v_cur[p].e[e], a.h);
+                        if (kHasM) m_cur[p].e[e] = mj;
+                    }
+                    g_cur[p].e[e] = g_cur[p].e[e] + s_cur[p].e[e];
+                }
+            }
+            int c = 0;
+            auto park = [&](const Pack<4>& v) {
+                f4 t;
+                t.x = v.e[0]; t.y = v.e[1]; t.z = v.e[2]; t.w = v.e[3];
+                stash[j][c++][p][threadIdx.x] = t;
+            };
+            if (MODE == kOutStepOnly) {
+                park(s_cur[p]);
+            } else {
+                park(g_cur[p]);
+                if (kHasV) park(v_cur[p]);
+                if (kHasM) park(m_cur[p]);
+                if (MODE == kOutFinalStep) park(s_cur[p]);
+            }
+        }
+        if (j == S - 1 || ct + 1 == ntiles) {
+            const unsigned first = ct - static_cast<unsigned>(j);
+#pragma unroll 1
+            for (int jj = 0; jj <= j; ++jj) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        const unsigned i = r0 + (first + jj) * kStashTile + p * kThreads + threadIdx.x;
+                        if (i < r1) burst_store(dst[c], nbytes, i, stash[jj][c][p][threadIdx.x]);
+                    }
+            }
+        }
+    };
+    auto consume = [&](Pack<4> (&x)[U][VPT]) {
+        if (ct >= ntiles) return;
+        if (cb == 0) {
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) {
+                g_cur[p] = g_nxt[p];
+                if (kHasV) v_cur[p] = v_nxt[p];
+                if (kHasM) m_cur[p] = m_nxt[p];
+                if (a.step_in) {
+                    s_cur[p] = s_nxt[p];
                 } else {
-                    park(r.g[p]);
-                    if (OPT != FA_OPT_NONE) park(r.v[p]);
-                    if (OPT >= FA_OPT_ADAM) park(r.m[p]);
-                    if (MODE == kOutFinalStep) park(r.s[p]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s_cur[p].e[e] = 0.0f;
                 }
             }
         }
-#pragma unroll 1
-        for (int j = 0; j < S; ++j) {
-            const unsigned base = tb + j * kStashTile;
-            if (base >= r1) break;
+        const int k0 = cb * U;
 #pragma unroll
-            for (int c = 0; c < NV; ++c)
+        for (int u = 0; u < U; ++u) {
+            if (k0 + u < a.K) {
+                const float wk = a.w[k0 + u];
 #pragma unroll
-                for (int p = 0; p < kStashVpt; ++p) {
-                    const unsigned i = base + p * kThreads + threadIdx.x;
-                    if (i < r1) burst_store(dst[c], nbytes, i, stash[j][c][p][threadIdx.x]);
+                for (int p = 0; p < VPT; ++p) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float d = x[u][p].e[e] - g_cur[p].e[e];
+                        float wd = d * wk;
+                        s_cur[p].e[e] = s_cur[p].e[e] + wd;
+                    }
                 }
+            }
         }
+        if (++cb == nb) {
+            cb = 0;
+            finish_tile();
+            ++ct;
+        }
+    };
+
+    issue(xa);
+    issue(xb);
+    while (ct < ntiles) {
+        consume(xa);
+        issue(xa);
+        consume(xb);
+        issue(xb);
     }
 }
 
@@ -639,7 +737,7 @@ int launch_reduce_u(const ReduceArgs& a, hipStream_t st) {
 template <int OPT, int VEC>
 int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
     if (VEC == 1) return launch_reduce_s<OPT, 1, 1, 8, true>(a, st);
-    if (g_shape.stash < 0 ||
+    if ((g_shape.stash < 0 && a.K > kStashUnroll) ||
         (g_shape.stash > 0 && a.K >= kStashMinClients &&
          a.n >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile))
         return launch_stash<OPT>(a, st);

@@ -233,7 +233,8 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from appfl_amd import workloads as W
@@ -245,7 +246,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -259,7 +260,7 @@ def main():
         b.step(evs[i])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -267,7 +268,7 @@ def main():
     kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
 
     extra = {}
-    if a.allgather and world > 1:
+    if a.allgather and use_dist:
         shard = b.result()
         full = torch.empty(world * shard.numel(), dtype=shard.dtype, device=shard.device)
         for _ in range(2):
@@ -326,7 +327,7 @@ def main():
             out["cpu_baseline"] = naive
             out["cpu_baseline_fused"] = fused
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void readk(const f4* __restrict__ p, size_t ro
 
 // (c) same pattern with the reduce arithmetic: s += (x - g) * w
 template <int U, int VPT, int MODE = 0>
-__global__ __launch_bounds__(256) void readk_math(const f4* __restrict__ p, size_t row4, int K, unsigned n4, const f4* __restrict__ gp, f4* __restrict__ gout, float w) {
+__global__ __launch_bounds__(256) void readk_math(const f4* __restrict__ p, size_t row4, int K, unsigned n4, const f4* __restrict__ gp, f4* __restrict__ gout, float w, unsigned wmask = 0xFFFF) {
     unsigned tiles = n4 / (256 * VPT);
     for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
         unsigned base = t * 256 * VPT + threadIdx.x;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void readk_math(const f4* __restrict__ p, size
                 for (int q = 0; q < VPT; ++q) acc[q] = acc[q] + (x[u][q] - g[q]) * w;
         }
         if (MODE == 0 || MODE == 3) { for (int q = 0; q < VPT; ++q) gout[base + q * 256] = g[q] + acc[q]; }
-        else if (MODE == 4) { for (int q = 0; q < VPT; ++q) gout[(base + q * 256) & 0xFFFF] = g[q] + acc[q]; }
+        else if (MODE == 4) { for (int q = 0; q < VPT; ++q) gout[(base + q * 256) & wmask] = g[q] + acc[q]; }
         else if (MODE == 5) { for (int q = 0; q < VPT; ++q) __builtin_nontemporal_store(g[q] + acc[q], gout + base + q * 256); }
         else { for (int q = 0; q < VPT; ++q) { f4 r = g[q] + acc[q]; if (r.x == 123.456f) gout[base + q * 256] = r; } }
     }
@@ -140,6 +140,11 @@ int main() {
         printf("readk_math store, no-g-load: %.3f ms %.0f GB/s client\n", ms, n * 4 / ms / 1e6);
         ms = timeit([&] { readk_math<8, 4, 4><<<r4 / 1024, 256>>>((const f4*)p, r4, K, r4, (const f4*)q, (f4*)q + r4, 0.015625f); });
         printf("readk_math store to 1MB window: %.3f ms %.0f GB/s client\n", ms, n * 4 / ms / 1e6);
+        for (unsigned mb : {1u, 4u, 16u, 32u, 64u}) {
+            unsigned mask = mb * 65536u - 1u;   // window of mb MiB in 16-byte vectors
+            ms = timeit([&] { readk_math<8, 4, 4><<<r4 / 1024, 256>>>((const f4*)p, r4, K, r4, (const f4*)q, (f4*)q + r4, 0.015625f, mask); });
+            printf("readk_math store to %u MiB window: %.3f ms %.0f GB/s client\n", mb, ms, n * 4 / ms / 1e6);
+        }
         ms = timeit([&] { readk_math<8, 4, 5><<<r4 / 1024, 256>>>((const f4*)p, r4, K, r4, (const f4*)q, (f4*)q + r4, 0.015625f); });
         printf("readk_math nt store: %.3f ms %.0f GB/s client\n", ms, n * 4 / ms / 1e6);
         ms = timeit([&] { readk_math<8, 4, 0><<<512, 256>>>((const f4*)p, r4, K, r4, (const f4*)q, (f4*)q + r4, 0.015625f); });

@@ -145,6 +145,58 @@ __global__ __launch_bounds__(256) void rk_pipe(const float* __restrict__ p, size
     }
 }
 
+// Adam-shaped traffic: per tile read g, m, v and write g, m, v (cheap stand-in arithmetic).
+// LAYOUT 0: three separate arrays; 1: one array interleaved per tile [tile][3][VPT*256 vectors].
+template <int STASH, int LAYOUT>
+__global__ __launch_bounds__(256) void rk_adam(const float* __restrict__ p, size_t row, int K, unsigned n4, float* __restrict__ st, float w) {
+    constexpr int U = 8, VPT = 4, TH = 256, NV = 3;
+    __shared__ f4 stash[STASH][NV][VPT][TH];
+    unsigned tiles = n4 / (TH * VPT);
+    unsigned per = (tiles + gridDim.x - 1) / gridDim.x;
+    unsigned t0 = blockIdx.x * per, t1 = min(tiles, t0 + per);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)st, 0, (int)(n4 * 16 * 3), 0x00020000);
+    auto off = [&](unsigned tile, int c, int q) -> unsigned {
+        if (LAYOUT == 0) return (unsigned)(((size_t)c * n4 + (size_t)tile * TH * VPT + q * TH + threadIdx.x) * 16);
+        return (unsigned)((((size_t)tile * NV + c) * TH * VPT + q * TH + threadIdx.x) * 16);
+    };
+    for (unsigned tb = t0; tb < t1; tb += STASH) {
+        unsigned cnt = min((unsigned)STASH, t1 - tb);
+        for (unsigned j = 0; j < cnt; ++j) {
+            unsigned base = ((tb + j) * TH * VPT + threadIdx.x) * 16;
+            f4 acc[VPT], g[VPT], m[VPT], v[VPT];
+            for (int q = 0; q < VPT; ++q) {
+                acc[q] = f4{0, 0, 0, 0};
+                g[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off(tb + j, 0, q), 0, 0));
+                m[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off(tb + j, 1, q), 0, 0));
+                v[q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, off(tb + j, 2, q), 0, 0));
+            }
+            for (int k = 0; k + U <= K; k += U) {
+                f4 x[U][VPT];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p + (size_t)(k + u) * row), 0, (int)(n4 * 16), 0x00020000);
+#pragma unroll
+                    for (int q = 0; q < VPT; ++q) x[u][q] = as_f4(__builtin_amdgcn_raw_buffer_load_b128(rx, base + q * (TH * 16), 0, 2));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int q = 0; q < VPT; ++q) acc[q] = acc[q] + (x[u][q] - g[q]) * w;
+            }
+            for (int q = 0; q < VPT; ++q) {
+                m[q] = m[q] * 0.9f + acc[q] * 0.1f;
+                v[q] = v[q] * 0.99f + acc[q] * acc[q] * 0.01f;
+                stash[j][0][q][threadIdx.x] = g[q] + m[q] * 0.1f;
+                stash[j][1][q][threadIdx.x] = m[q];
+                stash[j][2][q][threadIdx.x] = v[q];
+            }
+        }
+        for (unsigned j = 0; j < cnt; ++j)
+            for (int c = 0; c < NV; ++c)
+                for (int q = 0; q < VPT; ++q) __builtin_amdgcn_raw_buffer_store_b128(as_u4(stash[j][c][q][threadIdx.x]), rs, off(tb + j, c, q), 0, 17);
+    }
+}
+
 __global__ void fill_rand(unsigned* p, size_t n) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -191,9 +243,25 @@ void run_pipe(const char* name, int grid) {
     printf("%-44s %.3f ms %6.0f GB/s client\n", name, ms, n * 4 / ms / 1e6);
 }
 
+float* st3;
+template <int STASH, int LAYOUT>
+void run_adam(const char* name, int grid) {
+    unsigned r4 = row / 4;
+    float ms = timeit([&] { rk_adam<STASH, LAYOUT><<<grid, 256>>>(p, row, K, r4, st3, 0.015625f); });
+    CK(hipGetLastError());
+    printf("%-44s %.3f ms %6.0f GB/s client, alg %6.0f\n", name, ms, n * 4 / ms / 1e6, (n + 6 * row) * 4 / ms / 1e6);
+}
+
 int main() {
     CK(hipMalloc(&p, n * 4)); CK(hipMalloc(&q, row * 8)); CK(hipMalloc(&counter, 256));
     fill_rand<<<4096, 256>>>((unsigned*)p, n); fill_rand<<<4096, 256>>>((unsigned*)q, row * 2); CK(hipDeviceSynchronize());
+    CK(hipMalloc(&st3, row * 4 * 3)); CK(hipMemset(st3, 0, row * 4 * 3));
+    run_adam<3, 0>("adam traffic, separate g/m/v, stash 3", 256);
+    run_adam<3, 1>("adam traffic, interleaved per tile, stash 3", 256);
+    run_adam<1, 0>("adam traffic, separate, stash 1, grid 512", 512);
+    run_adam<1, 1>("adam traffic, interleaved, stash 1, grid 512", 512);
+    run_adam<3, 0>("adam traffic, separate g/m/v, stash 3 (again)", 256);
+    run_adam<3, 1>("adam traffic, interleaved, stash 3 (again)", 256);
     run<2, 0, 1>("load nt, store plain");
     run<2, 0, 1000000>("load nt, no store");
     run<2, 0, 2>("load nt, store plain, half volume");
@@ -230,6 +298,12 @@ int main() {
     run_stash<8, 17, false, 1024, 8, 1>("1024 thr, vpt 1, stash 8 x 16KB, sc0sc1", 256);
     run_stash<4, 17, false, 1024, 4, 2>("1024 thr, vpt 2 U=4, stash 4 x 32KB, sc0sc1", 256);
     run_stash<8, 17, false, 256, 16, 2>("256 thr, vpt 2 U=16, stash 8 x 8KB, sc0sc1", 256);
+    run_stash<4, 17>("stash 4 (64KB), sc0sc1, grid 512", 512);
+    run_stash<2, 17>("stash 2 (32KB), sc0sc1, grid 1024", 1024);
+    run_stash<1, 17>("stash 1 (16KB), sc0sc1, grid 1024", 1024);
+    run_stash<1, 17>("stash 1 (16KB), sc0sc1, grid 2048", 2048);
+    run_stash<4, 17, false, 256, 4, 4>("stash 4, U=4, sc0sc1, grid 512", 512);
+    run_stash<2, 17, false, 256, 4, 4>("stash 2, U=4, sc0sc1, grid 1024", 1024);
     run_pipe<8, 17, 4, 4>("pipelined 2x(U=4) vpt 4, stash 8, sc0sc1", 256);
     run_pipe<8, 17, 8, 2>("pipelined 2x(U=8) vpt 2, stash 8(x8KB), sc0sc1", 256);
     run_pipe<8, 17, 2, 4>("pipelined 2x(U=2) vpt 4, stash 8, sc0sc1", 256);
