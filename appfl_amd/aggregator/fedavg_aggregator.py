@@ -88,6 +88,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._v: Optional[torch.Tensor] = None
         self._step_flat: Optional[torch.Tensor] = None
         self._staged_for = None
+        self._prestaged: Dict[Any, tuple] = {}   # client_id -> (row, model) staged on arrival
+        self._row_of: list = []                  # slab row of the k-th client of this round
         self._chunks: Dict[tuple, "_ChunkState"] = {}    # streamed aggregation, one per key set
         self._dl = HostDownloader()
         self._init_lock()
@@ -203,17 +205,49 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 out.append(1.0 / len(local_models))
         return out
 
+    def stage(self, client_id, local_model) -> None:
+        """Optional hook for the scheduler: pack and upload ONE client's update the moment it
+        arrives (sync_scheduler.py:46 is where the reference merely stores it), so the PCIe
+        transfer overlaps the wait for the remaining clients.  `aggregate` reuses the staged
+        row when it later receives the same object for this client; not calling `stage` at all
+        is equally valid.  The first staged client of the first round initialises the global
+        state exactly as the first client of `aggregate` would (:228-271)."""
+        with self._lock:
+            if self._layout is None:
+                self._init_global_state(local_model)
+            row = len(self._prestaged)
+            hint = cfg_get(self.aggregator_configs, "num_clients", 0) or 0
+            self._slab.reserve(max(row + 1, int(hint)), preserve=row)
+            if row == 0:
+                self._slab.begin_round()
+            self._slab.upload(row, local_model, fill_missing_from=self._flats["f32"])
+            self._prestaged[client_id] = (row, local_model)
+
     def _stage(self, local_models) -> None:
         """Pack and upload every client's state dict into the device slab (client order =
-        dict order = arrival order, which is the reduction order)."""
+        dict order = arrival order, which is the reduction order); clients already uploaded by
+        `stage` keep their rows."""
         if self._staged_for is local_models:
             return
         K = len(local_models)
-        self._slab.reserve(K)
-        self._slab.begin_round()
-        for k, model in enumerate(local_models.values()):
-            self._slab.upload(k, model, fill_missing_from=self._flats["f32"])
+        taken = len(self._prestaged)
+        reuse = {cid: row for cid, (row, model) in self._prestaged.items()
+                 if cid in local_models and local_models[cid] is model}
+        fresh = K - len(reuse)
+        self._slab.reserve(taken + fresh, preserve=taken)
+        if taken == 0:
+            self._slab.begin_round()
+        self._row_of = []
+        nxt = taken
+        for cid, model in local_models.items():
+            if cid in reuse:
+                self._row_of.append(reuse[cid])
+                continue
+            self._slab.upload(nxt, model, fill_missing_from=self._flats["f32"])
+            self._row_of.append(nxt)
+            nxt += 1
         self._slab.end_round()
+        self._prestaged = {}
         self._staged_for = local_models
 
     def _hyper(self) -> Dict[str, float]:
@@ -223,7 +257,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         """Subclasses allocate m / v on the first round (e.g. fedadam_aggregator.py:41-50)."""
 
     def _rows(self, K: int, byte_offset: int):
-        return [self._slab.row_ptr(k) + byte_offset for k in range(K)]
+        rows = self._row_of if len(self._row_of) == K else range(K)
+        return [self._slab.row_ptr(r) + byte_offset for r in rows]
 
     # -- compute_steps: fedavg_aggregator.py:322-368 ------------------------------------------------
     @_native

@@ -36,6 +36,10 @@ class SerialSyncHarness:
         with self._access_lock:
             future: Future = Future()
             self.local_models[client_id] = local_model
+            # scheduler-side staging: start this client's upload while the others are awaited
+            stage = getattr(self.aggregator, "stage", None)
+            if callable(stage):
+                stage(client_id, local_model)
             for key, value in kwargs.items():
                 self.aggregation_kwargs.setdefault(key, {})[client_id] = value
             self.future[client_id] = future

@@ -34,12 +34,16 @@ class ClientSlab:
         self.next_slot = 0
         self.last_copy: Optional[torch.cuda.Event] = None
 
-    def reserve(self, rows: int) -> None:
+    def reserve(self, rows: int, preserve: int = 0) -> None:
+        """Room for `rows` client rows; the first `preserve` rows keep their contents when the
+        slab has to grow (clients staged on arrival, before the round's size is known)."""
         if rows <= self.capacity:
             return
+        if preserve:
+            rows = max(rows, 2 * self.capacity)
         need = rows * self.row_bytes
         free, _ = torch.cuda.mem_get_info(self.device)
-        have = 0 if self.slab is None else self.slab.numel()
+        have = 0 if (self.slab is None or preserve) else self.slab.numel()
         if need - have > free:
             raise MemoryError(
                 f"staging {rows} client updates needs {need / 2**30:.1f} GiB of device memory, "
@@ -47,8 +51,12 @@ class ClientSlab:
         # kernels of earlier rounds may still read the old slab on the compute stream
         torch.cuda.current_stream(self.device).synchronize()
         self.copy_stream.synchronize()
+        old = self.slab if preserve else None
         self.slab = None
         self.slab = torch.empty((rows, self.row_bytes), dtype=torch.uint8, device=self.device)
+        if old is not None:
+            self.slab[:preserve].copy_(old[:preserve])
+            torch.cuda.current_stream(self.device).synchronize()
         self.capacity = rows
 
     def row_ptr(self, k: int) -> int:

@@ -153,3 +153,24 @@ def test_config1_mnist_cnn_serial_harness_matches_oracle():
             got = outs[0][k].numpy() if isinstance(outs[0][k], torch.Tensor) else outs[0][k]
             assert golden_util.same_bits(got, outs[1][k]), (r, k)
     assert hs[0].get_num_global_epochs() == 3
+
+
+def test_staging_on_arrival_gives_the_same_round():
+    """stage() per arrival (also a partial set, a stale object, more clients than the hint) and
+    plain aggregate() produce identical bits."""
+    import appfl_amd.aggregator as A
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size", num_clients=2)
+    plain, staged = A.FedAdamAggregator(None, cfg, None), A.FedAdamAggregator(None, cfg, None)
+    for agg in (plain, staged):
+        for c in range(5):
+            agg.set_client_sample_size(c, 3 + 2 * c)
+    for r, K in enumerate([2, 5, 3]):
+        models = {c: S.make_state(S.RAGGED, seed=40 * r + c) for c in range(K)}
+        want = plain.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        for c in list(models)[: K - 1]:            # the last client is not pre-staged
+            staged.stage(c, models[c])
+        if r == 1:
+            models[1] = {k: v.clone() for k, v in models[1].items()}   # replaced after staging
+        got = staged.aggregate(models)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (r, k)
