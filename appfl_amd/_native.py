@@ -37,6 +37,7 @@ SIGNATURES = {
     "fa_reduce_step": (_i, [_p, _p, _i, _p, _p, _sz, _p]),
     "fa_server_opt_step": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _p]),
     "fa_apply_step": (_i, [_p, _p, _sz, _p]),
+    "fa_weighted_mix": (_i, [_p, _p, _i, _p, _d, _i, _p, _sz, _p]),
     "fa_mean_f32": (_i, [_p, _i, _p, _sz, _p]),
     "fa_mean_i64": (_i, [_p, _i, _p, _sz, _p]),
     "fa_mean_i32": (_i, [_p, _i, _p, _sz, _p]),

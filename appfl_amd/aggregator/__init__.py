@@ -4,6 +4,7 @@ from .base_aggregator import BaseAggregator
 from .fedavg_aggregator import (FedAdagradAggregator, FedAdamAggregator, FedAvgAggregator,
                                 FedAvgMAggregator, FedYogiAggregator)
 from .fedasync_aggregator import FedAsyncAggregator, FedBuffAggregator
+from .fedcompass_aggregator import FedCompassAggregator, FedQueueAggregator
 
 __all__ = [
     "BaseAggregator",
@@ -14,4 +15,6 @@ __all__ = [
     "FedAdagradAggregator",
     "FedAsyncAggregator",
     "FedBuffAggregator",
+    "FedCompassAggregator",
+    "FedQueueAggregator",
 ]

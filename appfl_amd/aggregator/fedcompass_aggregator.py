@@ -1,0 +1,240 @@
+"""FedCompass and FedQueue with the global model resident in HBM.
+
+Drop-in for algorithm/aggregator/fedcompass_aggregator.py:14-387 and
+algorithm/aggregator/fedqueue_aggregator.py:13-191 of the reference.  Both are weighted mixes
+of whole client models (no subtraction of the global model first):
+
+* FedCompass, one arrival:  g = g*(1 - a_t) + x*a_t          (gradient_based: g = g - x*a_t)
+* FedCompass, a group:      g = g*(1 - sum a_k) + sum x_k*a_k (gradient_based: sequential -=)
+* FedQueue:                 g = sum x_k*f_k, f normalised    (gradient_based: sequential -=)
+
+with a_k = alpha * staleness_fn(staleness_k) / num_clients and f_k = staleness_fn * data share.
+Entries that are integers or not `named_parameters` take the plain mean of the group (or, for
+a single FedCompass arrival, the client's value).  The scalar prologue is Python double
+arithmetic exactly as in the reference; one fa_weighted_mix launch does the rest.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, OrderedDict, Union
+
+import torch
+
+from .. import ops
+from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout
+from ..staging import ClientSlab, HostDownloader
+from .base_aggregator import BaseAggregator, DeviceStateMixin, cfg_get, resolve_device
+from .fedasync_aggregator import staleness_fn_factory
+
+
+class _MixAggregator(BaseAggregator, DeviceStateMixin):
+    def __init__(self, model: Optional[torch.nn.Module] = None, aggregator_configs: Any = None,
+                 logger: Optional[Any] = None):
+        self.model = model
+        self.logger = logger
+        self.aggregator_configs = aggregator_configs if aggregator_configs is not None else {}
+        self.optimize_memory = cfg_get(self.aggregator_configs, "optimize_memory", True)
+        if model is not None:
+            self.named_parameters = {name for name, _ in model.named_parameters()}
+        else:
+            self.named_parameters = None
+        self.device = resolve_device(self.aggregator_configs)
+        self._layout: Optional[Layout] = None
+        self._flats: Optional[Dict[str, torch.Tensor]] = None
+        self._slab: Optional[ClientSlab] = None
+        self._acc_ws: Optional[torch.Tensor] = None
+        self._dl = HostDownloader()
+        self._init_lock()
+
+    @property
+    def global_state(self) -> Optional[Dict[str, torch.Tensor]]:
+        if self._layout is None:
+            return None
+        return self._layout.views(self._flats)
+
+    def get_parameters(self, **kwargs) -> Dict:
+        with self._lock:
+            if self._layout is None:
+                if self.model is None:
+                    raise ValueError("Model is not provided to the aggregator.")
+                with torch.no_grad():
+                    return {k: v.clone().detach() for k, v in self.model.state_dict().items()}
+            return self._download()
+
+    def _download(self) -> Dict[str, torch.Tensor]:
+        lay = self._layout
+        host = {}
+        for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
+            host[key] = self._dl.fetch(self._flats[key], n)
+        return lay.views(host)
+
+    def _init_global_state(self, first_model):
+        """The model's entries for the names the first client sent, else the client's tensors
+        (fedcompass_aggregator.py:57-147, fedqueue_aggregator.py:45-71)."""
+        if self.model is not None:
+            model_state = self.model.state_dict()
+            init = {n: model_state[n] for n in first_model if n in model_state}
+        else:
+            init = dict(first_model)
+        self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
+                              self.named_parameters)
+        self._flats = self._layout.alloc_state(self.device)
+        with torch.no_grad():
+            for n, t in init.items():
+                self._layout.view(self._flats, n).copy_(t.detach())
+        self._slab = ClientSlab(self._layout, self.device)
+
+    def _stage(self, models) -> int:
+        K = len(models)
+        for m in models:
+            for e in self._layout.entries:
+                if e.name not in m:
+                    raise KeyError(e.name)
+        self._slab.reserve(K)
+        self._slab.begin_round()
+        for k, m in enumerate(models):
+            self._slab.upload(k, m)
+        self._slab.end_round()
+        return K
+
+    def _rows(self, K: int, byte_offset: int):
+        return [self._slab.row_ptr(k) + byte_offset for k in range(K)]
+
+    def _mix(self, K: int, weights, mode: str, coeff: float = 0.0) -> None:
+        n = self._layout.count[STEP]
+        if not n:
+            return
+        ws = None
+        if K > ops.kchunk() and mode != "subtract":
+            if self._acc_ws is None:
+                self._acc_ws = torch.empty(n, dtype=torch.float32, device=self.device)
+            ws = self._acc_ws
+        ops.weighted_mix(self._rows(K, 0), weights, self._flats["f32"], mode, coeff, acc_ws=ws, n=n)
+
+    def _plain_means(self, K: int) -> None:
+        lay, n_step = self._layout, self._layout.count[STEP]
+        if lay.count[MEAN_F32]:
+            ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), self._flats["f32"][n_step:],
+                     n=lay.count[MEAN_F32])
+        if lay.count[MEAN_I64]:
+            ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
+        if lay.count[MEAN_I32]:
+            ops.mean(self._rows(K, lay.seg_byte[MEAN_I32]), self._flats["i32"], n=lay.count[MEAN_I32])
+
+    def _replace_non_step(self) -> None:
+        lay, n_step = self._layout, self._layout.count[STEP]
+        for cls, key, dtype, lo in ((MEAN_F32, "f32", torch.float32, n_step),
+                                    (MEAN_I64, "i64", torch.int64, 0), (MEAN_I32, "i32", torch.int32, 0)):
+            cnt = lay.count[cls]
+            if cnt:
+                self._flats[key][lo:lo + cnt].copy_(self._slab.row_view(0, lay.seg_byte[cls], cnt, dtype))
+
+    def _finish(self) -> Dict[str, torch.Tensor]:
+        out = self._download()
+        self._sync_model(self.model, out)
+        return out
+
+
+class FedCompassAggregator(_MixAggregator):
+    """FedCompass (https://arxiv.org/abs/2309.14675).  Configuration fields: `alpha`,
+    `staleness_fn` (constant | polynomial | hinge), `staleness_fn_kwargs`, `num_clients`,
+    `gradient_based`."""
+
+    def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
+        super().__init__(model, aggregator_configs, logger)
+        kw = cfg_get(self.aggregator_configs, "staleness_fn_kwargs", None) or {}
+        self.staleness_fn = staleness_fn_factory(
+            staleness_fn_name=cfg_get(self.aggregator_configs, "staleness_fn", "constant"), **dict(kw))
+        self.alpha = cfg_get(self.aggregator_configs, "alpha", 0.9)
+
+    def aggregate(self, client_id: Optional[Union[str, int]] = None,
+                  local_model: Optional[Union[Dict, OrderedDict]] = None,
+                  local_models: Optional[Dict[Union[str, int], Union[Dict, OrderedDict]]] = None,
+                  staleness: Optional[Union[int, Dict[Union[str, int], int]]] = None,
+                  **kwargs) -> Dict:
+        gb = cfg_get(self.aggregator_configs, "gradient_based", False)
+        weight = 1.0 / cfg_get(self.aggregator_configs, "num_clients", 1)
+        with self._lock:
+            if client_id is not None and local_model is not None:
+                # one arrival: fedcompass_aggregator.py:152-206
+                if self._layout is None:
+                    self._init_global_state(local_model)
+                self._stage([local_model])
+                alpha_t = self.alpha * self.staleness_fn(staleness) * weight
+                if gb:
+                    self._mix(1, [alpha_t], "subtract")
+                else:
+                    self._mix(1, [alpha_t], "convex_one", 1 - alpha_t)
+                self._replace_non_step()
+                return self._finish()
+            # a group of clients: fedcompass_aggregator.py:208-338
+            if self._layout is None:
+                self._init_global_state(next(iter(local_models.values())))
+            K = self._stage(list(local_models.values()))
+            alphas, alpha_t_sum = [], 0
+            for cid in local_models:
+                alpha_t = self.alpha * self.staleness_fn(staleness[cid]) * weight
+                alpha_t_sum += alpha_t
+                alphas.append(alpha_t)
+            if gb:
+                self._mix(K, alphas, "subtract")
+            else:
+                self._mix(K, alphas, "convex", 1 - alpha_t_sum)
+            self._plain_means(K)
+            return self._finish()
+
+
+def _queue_staleness_fn_factory(staleness_fn_name, **kwargs):
+    """fedqueue_aggregator.py:177-191."""
+    if staleness_fn_name == "constant":
+        return lambda u: 1.0
+    elif staleness_fn_name == "harmonic":
+        beta = kwargs["beta"]
+        return lambda u: 1.0 / (1.0 + beta * u)
+    elif staleness_fn_name == "exponential":
+        beta = kwargs["beta"]
+        return lambda u: torch.exp(-beta * u)
+    else:
+        raise NotImplementedError
+
+
+class FedQueueAggregator(_MixAggregator):
+    """FedQueue: data-size client weights with staleness decay, normalised over the group.
+    Configuration fields: `staleness_fn` (constant | harmonic | exponential),
+    `staleness_fn_kwargs` {beta}, `gradient_based`."""
+
+    def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
+        super().__init__(model, aggregator_configs, logger)
+        kw = cfg_get(self.aggregator_configs, "staleness_fn_kwargs", None) or {}
+        self.staleness_fn = _queue_staleness_fn_factory(
+            cfg_get(self.aggregator_configs, "staleness_fn", "constant"), **dict(kw))
+
+    def _get_aggregation_factors(self, local_models, staleness) -> Dict:
+        """fedqueue_aggregator.py:138-169."""
+        sizes = getattr(self, "client_sample_size", None)
+        if sizes is not None and all(cid in sizes for cid in local_models):
+            total = sum(sizes[cid] for cid in local_models)
+            if total > 0:
+                return {cid: self.staleness_fn(staleness[cid]) * (sizes[cid] / total)
+                        for cid in local_models}
+        if self.logger is not None:
+            self.logger.warning(
+                "FedQueueAggregator did not receive sample sizes for all participating clients; "
+                "falling back to equal client weights.")
+        return {cid: self.staleness_fn(staleness[cid]) * (1.0 / len(local_models))
+                for cid in local_models}
+
+    def aggregate(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict]],
+                  staleness: Dict[Union[str, int], int],
+                  local_steps: Optional[Dict[Union[str, int], int]] = None) -> Dict:
+        with self._lock:
+            if self._layout is None:
+                self._init_global_state(next(iter(local_models.values())))
+            gb = cfg_get(self.aggregator_configs, "gradient_based", False)
+            factors = self._get_aggregation_factors(local_models, staleness)
+            total = sum(factors.values())
+            factors = {cid: f / total for cid, f in factors.items()}
+            K = self._stage(list(local_models.values()))
+            self._mix(K, [float(factors[cid]) for cid in local_models], "subtract" if gb else "replace")
+            self._plain_means(K)
+            return self._finish()

@@ -515,6 +515,91 @@ __global__ __launch_bounds__(kThreads) void mean_kernel(const MeanArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weighted mixes of K client vectors that do not subtract g first (FedCompass / FedQueue).
+
+struct MixArgs {
+    const float* x[FA_KCHUNK];
+    float w[FA_KCHUNK];
+    float* g;
+    const float* acc_in;  // partial sum of earlier client chunks (NULL: 0); modes 0 / 1
+    float* acc_out;       // where a non-final chunk leaves its partial sum
+    unsigned n;           // elements of width VEC
+    int K;
+    int mode;             // FA_MIX_*
+    int last;
+    float coeff;
+};
+
+template <int VEC, int VPT, int U>
+__global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
+    constexpr unsigned kTile = kThreads * VPT;
+    const unsigned tiles = (a.n + kTile - 1) / kTile;
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+        unsigned idx[VPT];
+        bool ok[VPT];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            unsigned i = t * kTile + p * kThreads + threadIdx.x;
+            ok[p] = i < a.n;
+            idx[p] = ok[p] ? i : a.n - 1;
+        }
+        Pack<VEC> acc[VPT], g[VPT];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            if (a.mode != FA_MIX_REPLACE) g[p] = load_state<VEC>(a.g, idx[p]);
+            if (a.mode == FA_MIX_SUBTRACT) {
+                acc[p] = g[p];
+            } else if (a.acc_in) {
+                acc[p] = load_state<VEC>(a.acc_in, idx[p]);
+            } else {
+                // -0 + y == y for every y, so the single-arrival form adds x*w to nothing
+                const float zero = (a.mode == FA_MIX_CONVEX_ONE) ? -0.0f : 0.0f;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[p].e[j] = zero;
+            }
+        }
+        auto fold = [&](const Pack<VEC>& x, int p, float wk) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float xw = x.e[j] * wk;
+                acc[p].e[j] = (a.mode == FA_MIX_SUBTRACT) ? acc[p].e[j] - xw : acc[p].e[j] + xw;
+            }
+        };
+        int k = 0;
+        for (; k + U <= a.K; k += U) {
+            Pack<VEC> xv[U][VPT];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) xv[u][p] = load_stream<VEC, true>(a.x[k + u], idx[p]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) fold(xv[u][p], p, a.w[k + u]);
+        }
+        for (; k < a.K; ++k)
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) fold(load_stream<VEC, true>(a.x[k], idx[p]), p, a.w[k]);
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            if (!ok[p]) continue;
+            if (!a.last && a.mode != FA_MIX_SUBTRACT) {
+                store_result(a.acc_out, idx[p], acc[p], 1);
+                continue;
+            }
+            if ((a.mode == FA_MIX_CONVEX || a.mode == FA_MIX_CONVEX_ONE) && a.last) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float gt = g[p].e[j] * a.coeff;
+                    acc[p].e[j] = gt + acc[p].e[j];
+                }
+            }
+            store_result(a.g, idx[p], acc[p], 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Elementwise kernels: apply, FedAsync mix, FedBuff accumulate / flush, fills.
 
 template <int VEC>
@@ -1081,6 +1166,54 @@ int fa_server_opt_step(float* step, float* m, float* v, size_t n, int opt, doubl
         }
 #undef FA_LAUNCH_OPT
         return launch_status();
+    });
+}
+
+int fa_weighted_mix(const float* const* x, const double* w, int K, float* g, double coeff,
+                    int mode, float* acc_ws, size_t n, fa_stream_t stream) {
+    if (!x || !w || !g || K <= 0) return FA_ERR_INVALID;
+    if (mode < FA_MIX_REPLACE || mode > FA_MIX_CONVEX_ONE) return FA_ERR_INVALID;
+    if (mode == FA_MIX_CONVEX_ONE && K != 1) return FA_ERR_INVALID;
+    if (K > FA_KCHUNK && mode != FA_MIX_SUBTRACT && !acc_ws) return FA_ERR_WORKSPACE;
+    if (n == 0) return FA_OK;
+    bool a4 = aligned_to(g, 4) && (!acc_ws || aligned_to(acc_ws, 4));
+    bool a16 = aligned16(g) && (!acc_ws || aligned16(acc_ws));
+    for (int k = 0; k < K; ++k) {
+        if (!x[k]) return FA_ERR_INVALID;
+        a4 = a4 && aligned_to(x[k], 4);
+        a16 = a16 && aligned16(x[k]);
+    }
+    if (!a4) return FA_ERR_ALIGN;
+    hipStream_t st = as_stream(stream);
+    const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
+    return for_each_range(n, a16, [&](size_t off, size_t cnt, bool vec) {
+        for (int ch = 0; ch < chunks; ++ch) {
+            MixArgs a;
+            memset(&a, 0, sizeof(a));
+            const int k0 = ch * FA_KCHUNK;
+            a.K = (K - k0 < FA_KCHUNK) ? K - k0 : FA_KCHUNK;
+            for (int k = 0; k < a.K; ++k) {
+                a.x[k] = x[k0 + k] + off;
+                a.w[k] = static_cast<float>(w[k0 + k]);
+            }
+            a.g = g + off;
+            a.acc_in = (ch == 0 || mode == FA_MIX_SUBTRACT) ? nullptr : acc_ws + off;
+            a.acc_out = acc_ws ? acc_ws + off : nullptr;
+            a.n = static_cast<unsigned>(cnt);
+            a.mode = mode;
+            a.last = (ch == chunks - 1);
+            a.coeff = static_cast<float>(coeff);
+            if (vec) {
+                size_t tiles = (cnt + kThreads * 4 - 1) / (kThreads * 4);
+                hipLaunchKernelGGL((mix_kernel<4, 4, 8>), dim3(static_cast<unsigned>(tiles > size_t(kMaxBlocks) ? kMaxBlocks : tiles)),
+                                   dim3(kThreads), 0, st, a);
+            } else {
+                hipLaunchKernelGGL((mix_kernel<1, 1, 8>), dim3(grid_for(cnt)), dim3(kThreads), 0, st, a);
+            }
+            int rc = launch_status();
+            if (rc != FA_OK) return rc;
+        }
+        return static_cast<int>(FA_OK);
     });
 }
 

@@ -129,6 +129,22 @@ def apply_step(g, step, n: Optional[int] = None) -> None:
                                    _stream(g)), "fa_apply_step")
 
 
+MIX_MODES = {"replace": 0, "convex": 1, "subtract": 2, "convex_one": 3}
+
+
+def weighted_mix(x: Sequence, w: Sequence[float], g: torch.Tensor, mode: str, coeff: float = 0.0,
+                 acc_ws: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
+    """FedCompass / FedQueue mixes over ``g[:n]`` (fa_weighted_mix)."""
+    n = g.numel() if n is None else n
+    if len(x) != len(w):
+        raise ValueError("one weight per client buffer")
+    rc = N.load().fa_weighted_mix(_check_rows(x, n, torch.float32),
+                                  N.double_array([float(t) for t in w]), len(x),
+                                  _dev(g, torch.float32), float(coeff), MIX_MODES[mode],
+                                  _dev(acc_ws, torch.float32), n, _stream(g))
+    N.check(rc, "fa_weighted_mix")
+
+
 _MEAN = {torch.float32: "fa_mean_f32", torch.int64: "fa_mean_i64", torch.int32: "fa_mean_i32"}
 _RAW = {torch.float32: "fa_buff_accum_raw_f32", torch.int64: "fa_buff_accum_raw_i64",
         torch.int32: "fa_buff_accum_raw_i32"}

@@ -22,7 +22,8 @@ from typing import Dict, Optional
 from . import aggregator as _dev
 
 NAMES = ("FedAvgAggregator", "FedAvgMAggregator", "FedAdamAggregator", "FedYogiAggregator",
-         "FedAdagradAggregator", "FedAsyncAggregator", "FedBuffAggregator")
+         "FedAdagradAggregator", "FedAsyncAggregator", "FedBuffAggregator",
+         "FedCompassAggregator", "FedQueueAggregator")
 
 
 def register(prefix: str = "MI355X", replace: bool = False, module=None) -> Dict[str, type]:

@@ -132,6 +132,22 @@ int fa_mean_i64(const int64_t* const* x, int K, int64_t* g, size_t n, fa_stream_
 int fa_mean_i32(const int32_t* const* x, int K, int32_t* g, size_t n, fa_stream_t stream);
 
 /*
+ * Weighted mixes that do not subtract g first -- FedCompass and FedQueue
+ * (algorithm/aggregator/fedcompass_aggregator.py:152-338, fedqueue_aggregator.py:75-131):
+ *   acc = 0;  for k in 0..K-1:  acc = acc + x[k][i] * (float)w[k]
+ *   FA_MIX_REPLACE:  g = acc                              (FedQueue, model-based)
+ *   FA_MIX_CONVEX:   g = g * (float)coeff + acc           (FedCompass group; coeff = 1 - sum w)
+ *   FA_MIX_SUBTRACT: for k: g = g - x[k][i] * (float)w[k] (gradient_based form of both)
+ *   FA_MIX_CONVEX_ONE (K = 1): g = g * (float)coeff + x[0][i] * (float)w[0]  -- FedCompass's
+ *                    single arrival, which adds to no zero accumulator (sign of a zero result)
+ * x, w: HOST arrays as in fa_reduce_opt.  acc_ws: n-float workspace, only needed when
+ * K > FA_KCHUNK in the first two modes.
+ */
+enum { FA_MIX_REPLACE = 0, FA_MIX_CONVEX = 1, FA_MIX_SUBTRACT = 2, FA_MIX_CONVEX_ONE = 3 };
+int fa_weighted_mix(const float* const* x, const double* w, int K, float* g, double coeff,
+                    int mode, float* acc_ws, size_t n, fa_stream_t stream);
+
+/*
  * FedAsync arrival (algorithm/aggregator/fedasync_aggregator.py:243-264 and :156-160).
  *   gradient_based == 0:  step = (float)alpha_t * (x - g)
  *   gradient_based == 1:  step = 0 - (float)alpha_t * x      (sub_form == 1, optimize_memory)

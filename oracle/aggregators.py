@@ -404,6 +404,152 @@ class OracleFedBuff(OracleFedAsync):
         return {k: v.copy() for k, v in self.global_state.items()}
 
 
+class _OracleMixBase(OracleBase):
+    """Shared state handling of FedCompass / FedQueue."""
+
+    def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
+        self.model = model
+        self.cfg = aggregator_configs or {}
+        self.model_state, self.named_parameters = _model_info(model)
+        self.global_state = None
+
+    def get_parameters(self, **kwargs):
+        if self.global_state is None:
+            if self.model_state is None:
+                raise ValueError("Model is not provided to the aggregator.")
+            return {k: v.copy() for k, v in self.model_state.items()}
+        return {k: v.copy() for k, v in self.global_state.items()}
+
+    def _init_global(self, first):
+        if self.model_state is not None:
+            self.global_state = {n: self.model_state[n].copy() for n in first if n in self.model_state}
+        else:
+            self.global_state = {n: t.copy() for n, t in first.items()}
+
+    def _is_step_name(self, name) -> bool:
+        if self.named_parameters is not None and name not in self.named_parameters:
+            return False
+        return self.global_state[name].dtype not in _INT
+
+    def _plain_mean(self, name, local_models):
+        first = next(iter(local_models.values()))[name]
+        s = np.zeros_like(first)
+        for m in local_models.values():
+            s = s + m[name]
+        k = len(local_models)
+        return _int_div(s, k) if s.dtype in _INT else (s / s.dtype.type(k)).astype(s.dtype)
+
+    def _finish(self):
+        if self.model_state is not None:
+            for k, v in self.global_state.items():
+                if k in self.model_state:
+                    self.model_state[k] = v.copy()
+        return {k: v.copy() for k, v in self.global_state.items()}
+
+
+class OracleFedCompass(_OracleMixBase):
+    """fedcompass_aggregator.py:14-387."""
+
+    def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
+        super().__init__(model, aggregator_configs, logger)
+        self.staleness_fn = staleness_fn_factory(
+            cfg_get(self.cfg, "staleness_fn", "constant"),
+            **dict(cfg_get(self.cfg, "staleness_fn_kwargs", {}) or {}))
+        self.alpha = cfg_get(self.cfg, "alpha", 0.9)
+
+    def aggregate(self, client_id=None, local_model=None, local_models=None, staleness=None, **kw):
+        gb = cfg_get(self.cfg, "gradient_based", False)
+        weight = 1.0 / cfg_get(self.cfg, "num_clients", 1)
+        if client_id is not None and local_model is not None:
+            local_model = {k: to_np(v) for k, v in local_model.items()}
+            if self.global_state is None:
+                self._init_global(local_model)
+            alpha_t = self.alpha * self.staleness_fn(staleness) * weight      # :153-154
+            for name in self.global_state:
+                if not self._is_step_name(name):
+                    self.global_state[name] = local_model[name].copy()          # :166
+                elif gb:
+                    self.global_state[name] = self.global_state[name] - local_model[name] * _f32(alpha_t)
+                else:                                                           # :177-181
+                    self.global_state[name] = self.global_state[name] * _f32(1 - alpha_t) \
+                        + local_model[name] * _f32(alpha_t)
+            return self._finish()
+        local_models = {c: {k: to_np(v) for k, v in m.items()} for c, m in local_models.items()}
+        if self.global_state is None:
+            self._init_global(next(iter(local_models.values())))
+        acc = {n: np.zeros_like(g) for n, g in self.global_state.items()}
+        alpha_t_sum = 0
+        for i, cid in enumerate(local_models):                                  # :223-287
+            alpha_t = self.alpha * self.staleness_fn(staleness[cid]) * weight
+            alpha_t_sum += alpha_t
+            for name in self.global_state:
+                if not self._is_step_name(name):
+                    continue
+                if gb:
+                    self.global_state[name] = self.global_state[name] - local_models[cid][name] * _f32(alpha_t)
+                else:
+                    acc[name] = acc[name] + local_models[cid][name] * _f32(alpha_t)
+        for name in list(self.global_state):
+            if not self._is_step_name(name):
+                self.global_state[name] = self._plain_mean(name, local_models)
+            elif not gb:
+                self.global_state[name] = self.global_state[name] * _f32(1 - alpha_t_sum) + acc[name]
+        return self._finish()
+
+
+def queue_staleness_fn_factory(name, **kwargs):
+    """fedqueue_aggregator.py:177-191 (the `exponential` branch of the reference calls
+    torch.exp on a Python number and cannot run; it is not restated)."""
+    if name == "constant":
+        return lambda u: 1.0
+    if name == "harmonic":
+        beta = kwargs["beta"]
+        return lambda u: 1.0 / (1.0 + beta * u)
+    raise NotImplementedError
+
+
+class OracleFedQueue(_OracleMixBase):
+    """fedqueue_aggregator.py:13-191."""
+
+    def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
+        super().__init__(model, aggregator_configs, logger)
+        self.staleness_fn = queue_staleness_fn_factory(
+            cfg_get(self.cfg, "staleness_fn", "constant"),
+            **dict(cfg_get(self.cfg, "staleness_fn_kwargs", {}) or {}))
+
+    def _factors(self, local_models, staleness):
+        sizes = getattr(self, "client_sample_size", None)
+        if sizes is not None and all(c in sizes for c in local_models):
+            total = sum(sizes[c] for c in local_models)
+            if total > 0:
+                return {c: self.staleness_fn(staleness[c]) * (sizes[c] / total) for c in local_models}
+        return {c: self.staleness_fn(staleness[c]) * (1.0 / len(local_models)) for c in local_models}
+
+    def aggregate(self, local_models, staleness, local_steps=None):
+        local_models = {c: {k: to_np(v) for k, v in m.items()} for c, m in local_models.items()}
+        if self.global_state is None:
+            self._init_global(next(iter(local_models.values())))
+        gb = cfg_get(self.cfg, "gradient_based", False)
+        f = self._factors(local_models, staleness)
+        fsum = sum(f.values())
+        f = {c: v / fsum for c, v in f.items()}                                 # :76-80
+        acc = {n: np.zeros_like(g) for n, g in self.global_state.items()}
+        for cid, m in local_models.items():
+            for name in self.global_state:
+                if not self._is_step_name(name):
+                    continue
+                if gb:
+                    self.global_state[name] = self.global_state[name] - m[name] * _f32(f[cid])
+                else:
+                    acc[name] = acc[name] + m[name] * _f32(f[cid])
+        for name in list(self.global_state):
+            if not self._is_step_name(name):
+                self.global_state[name] = self._plain_mean(name, local_models)
+            elif not gb:
+                self.global_state[name] = acc[name]
+        return self._finish()
+
+
 ORACLES = {
     "FedAvgAggregator": OracleFedAvg,
     "FedAvgMAggregator": OracleFedAvgM,
@@ -412,4 +558,6 @@ ORACLES = {
     "FedAdagradAggregator": OracleFedAdagrad,
     "FedAsyncAggregator": OracleFedAsync,
     "FedBuffAggregator": OracleFedBuff,
+    "FedCompassAggregator": OracleFedCompass,
+    "FedQueueAggregator": OracleFedQueue,
 }

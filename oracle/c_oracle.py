@@ -81,6 +81,13 @@ def server_opt_step(step, m, v, opt, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0) -> N
     assert rc == 0, rc
 
 
+def weighted_mix(x, w, g, mode, coeff=0.0) -> None:
+    wa = (C.c_double * len(w))(*[float(t) for t in w])
+    rc = load().or_weighted_mix(_ptrs(x), wa, C.c_int(len(x)), _ptr(_chk(g, np.float32)),
+                                C.c_double(coeff), C.c_int(mode), C.c_size_t(g.size))
+    assert rc == 0, rc
+
+
 def apply_step(g, step) -> None:
     load().or_apply_step(_ptr(_chk(g, np.float32)), _ptr(_chk(step, np.float32)),
                          C.c_size_t(g.size))

@@ -178,6 +178,34 @@ void or_mean_i32(const int32_t* const* x, int K, int32_t* g, size_t n) {
     }
 }
 
+/* fedcompass_aggregator.py:152-338 / fedqueue_aggregator.py:75-131.
+ * mode 0: g = sum x*w;  1: g = g*coeff + sum x*w;  2: g = g - x0*w0 - x1*w1 ...;
+ * 3 (K = 1): g = g*coeff + x0*w0 with no zero accumulator (single FedCompass arrival). */
+int or_weighted_mix(const float* const* x, const double* w, int K, float* g, double coeff, int mode,
+                    size_t n) {
+    if (K <= 0 || K > 65536 || mode < 0 || mode > 3 || (mode == 3 && K != 1)) return -1;
+    float wf[K];
+    for (int k = 0; k < K; ++k) wf[k] = (float)w[k];
+    const float c = (float)coeff;
+    for (size_t i = 0; i < n; ++i) {
+        float acc = (mode == 2) ? g[i] : 0.0f;
+        if (mode == 3) {
+            acc = x[0][i] * wf[0];
+        } else {
+            for (int k = 0; k < K; ++k) {
+                float xw = x[k][i] * wf[k];
+                acc = (mode == 2) ? acc - xw : acc + xw;
+            }
+        }
+        if (mode == 1 || mode == 3) {
+            float gt = g[i] * c;
+            acc = gt + acc;
+        }
+        g[i] = acc;
+    }
+    return 0;
+}
+
 /* mode 0: alpha*(x-g); mode 1: 0 - alpha*x (sub_ with alpha on zeros); mode 2: alpha*(-x). */
 static inline float async_step(float x, float g, float alpha, int mode) {
     if (mode == 0) {

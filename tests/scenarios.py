@@ -230,8 +230,38 @@ def chunk_keys_by_size(spec: Dict, max_bytes: int) -> List[List[str]]:
     return chunks
 
 
+# (kind of call, clients, staleness per client): FedCompass mixes single arrivals and groups
+COMPASS_SCRIPT = [("single", [0], [0]), ("group", [1, 2], [1, 3]), ("single", [2], [2]),
+                  ("group", [0, 1, 2], [0, 4, 1]), ("single", [1], [5])]
+QUEUE_SCRIPT = [([0, 1], [0, 1]), ([2], [3]), ([1, 2, 0], [2, 0, 4])]
+
+
+def mix_scenarios() -> List[Dict]:
+    """FedCompass (fedcompass_aggregator.py) and FedQueue (fedqueue_aggregator.py)."""
+    out = []
+    for gb, with_model, optmem in itertools.product((False, True), (False, True), (True, False)):
+        cfg = dict(STALENESS["polynomial"], alpha=0.9, num_clients=3, gradient_based=gb,
+                   optimize_memory=optmem)
+        out.append({"id": f"FedCompass-{'grad' if gb else 'model'}-"
+                          f"{'model' if with_model else 'nomodel'}-{'opt' if optmem else 'orig'}",
+                    "kind": "compass", "cls": "FedCompassAggregator", "spec": "toy",
+                    "model": with_model, "cfg": cfg, "sample_sizes": {}})
+    out.append({"id": "FedCompass-ragged-hinge", "kind": "compass", "cls": "FedCompassAggregator",
+                "spec": "ragged", "model": False,
+                "cfg": dict(STALENESS["hinge"], alpha=0.5, num_clients=4), "sample_sizes": {}})
+    for gb, with_model, sized in itertools.product((False, True), (False, True), (True, False)):
+        cfg = {"staleness_fn": "harmonic", "staleness_fn_kwargs": {"beta": 0.5}, "gradient_based": gb}
+        out.append({"id": f"FedQueue-{'grad' if gb else 'model'}-{'model' if with_model else 'nomodel'}-"
+                          f"{'sized' if sized else 'equal'}",
+                    "kind": "queue", "cls": "FedQueueAggregator", "spec": "toy", "model": with_model,
+                    "cfg": cfg, "sample_sizes": {0: 12, 1: 30, 2: 7} if sized else {}})
+    out.append({"id": "FedQueue-ragged-constant", "kind": "queue", "cls": "FedQueueAggregator",
+                "spec": "ragged", "model": False, "cfg": {}, "sample_sizes": {0: 5, 1: 9, 2: 2}})
+    return out
+
+
 def all_scenarios() -> List[Dict]:
-    return sync_scenarios() + async_scenarios() + chunked_scenarios()
+    return sync_scenarios() + async_scenarios() + chunked_scenarios() + mix_scenarios()
 
 
 def _state_snapshots(agg) -> List[Tuple[str, Dict]]:
@@ -275,6 +305,27 @@ def run_scenario(factory: Callable, sc: Dict) -> List[Tuple[str, Dict[str, np.nd
             for lbl, d in _state_snapshots(agg):
                 rec.append((f"round{r}.{lbl}", d))
             rec.append((f"round{r}", _snap(out)))
+        rec.append(("final_get_parameters", _snap(agg.get_parameters())))
+    elif sc["kind"] == "compass":
+        gb = sc["cfg"].get("gradient_based", False)
+        for i, (how, cids, stale) in enumerate(COMPASS_SCRIPT):
+            states = {c: make_state(spec, seed=4000 + 31 * i + c, gradient=gb,
+                                    scale=0.01 if gb else 0.02) for c in cids}
+            if how == "single":
+                out = agg.aggregate(client_id=cids[0], local_model=states[cids[0]], staleness=stale[0],
+                                    local_steps=7)
+            else:
+                out = agg.aggregate(local_models=states, staleness=dict(zip(cids, stale)),
+                                    local_steps={c: 7 for c in cids})
+            rec.append((f"call{i}.{how}", _snap(out)))
+        rec.append(("final_get_parameters", _snap(agg.get_parameters())))
+    elif sc["kind"] == "queue":
+        gb = sc["cfg"].get("gradient_based", False)
+        for i, (cids, stale) in enumerate(QUEUE_SCRIPT):
+            states = {c: make_state(spec, seed=5000 + 31 * i + c, gradient=gb,
+                                    scale=0.01 if gb else 0.02) for c in cids}
+            out = agg.aggregate(states, dict(zip(cids, stale)), {c: 3 for c in cids})
+            rec.append((f"call{i}", _snap(out)))
         rec.append(("final_get_parameters", _snap(agg.get_parameters())))
     elif sc["kind"] == "chunked":
         chunks = chunk_keys_by_size(spec, sc["chunk_bytes"])

@@ -332,3 +332,20 @@ def test_persistent_stash_kernel_with_client_chunks():
     assert_bits(g, g_ref, "g")
     assert_bits(m, m_ref, "m")
     assert_bits(v, v_ref, "v")
+
+
+@pytest.mark.parametrize("mode,code", [("replace", 0), ("convex", 1), ("subtract", 2), ("convex_one", 3)])
+@pytest.mark.parametrize("n,K", [(5, 1), (4099, 3), (300007, 9), (2051, 131)])
+def test_weighted_mix(mode, code, n, K):
+    from appfl_amd import ops
+    if mode == "convex_one":
+        K = 1
+    base, xs = make_clients(n, K)
+    w = [0.9 * (k + 1) ** -0.5 / 7 for k in range(K)]
+    coeff = 1 - sum(w)
+    g_ref = base.copy()
+    O.weighted_mix(xs, w, g_ref, code, coeff)
+    g = dev(base)
+    ws = torch.empty_like(g) if K > ops.kchunk() else None
+    ops.weighted_mix([dev(x) for x in xs], w, g, mode, coeff, acc_ws=ws)
+    assert_bits(g, g_ref, "g")
