@@ -322,8 +322,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             return self._aggregate_chunk(local_models, **kwargs)
         if secure_enabled and all(isinstance(m, dict) and m.get("type") == "masked_update_flat"
                                   for m in local_models.values()):
-            raise NotImplementedError(
-                "secure-aggregation payloads are not implemented on the MI355X path yet")
+            return self._aggregate_masked_flat(local_models)
         with self._lock:
             first = next(iter(local_models.values()))
             if self._layout is None:
@@ -340,6 +339,58 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._sync_model(self.model, out)
             return out
 
+
+    # -- secure-aggregation payloads: fedavg_aggregator.py:171-225 ------------------------------------
+    def _aggregate_masked_flat(self, local_models) -> Dict:
+        """Clients sent `{"type": "masked_update_flat", "flat", "shapes", "num_examples"}`: the
+        pairwise masks cancel in the weighted sum of the flat fp32 vectors, which is ADDED to the
+        global state (or becomes it on the first round).  The flat vector keeps the clients'
+        entry order (`shapes`), so this path has a layout of its own in which every entry is
+        fp32 and takes the sum."""
+        with self._lock:
+            payloads = list(local_models.values())
+            shapes = [(name, tuple(int(d) for d in shp)) for name, shp in payloads[0]["shapes"]]
+            first_round = self._layout is None
+            if first_round:
+                self._layout = Layout([(n, shp, torch.float32) for n, shp in shapes], None)
+                self._flats = self._layout.alloc_state(self.device)
+                self._slab = ClientSlab(self._layout, self.device)
+                self._secure_layout = True
+            elif not getattr(self, "_secure_layout", False) or \
+                    self._layout.names != [n for n, _ in shapes]:
+                raise NotImplementedError(
+                    "mixing secure-aggregation payloads with plain state dicts (or changing the "
+                    "payload's entries) on one aggregator is not supported on the MI355X path")
+            n = self._layout.n_f32
+            K = len(payloads)
+            total_examples = sum(p["num_examples"] for p in payloads)
+            weights = []
+            for p in payloads:
+                if self.client_weights_mode == "sample_size":
+                    weights.append(float(p["num_examples"]) / float(total_examples))
+                else:
+                    weights.append(1.0 / K)
+            self._slab.reserve(K)
+            self._slab.begin_round()
+            with torch.cuda.stream(self._slab.copy_stream):
+                for k, p in enumerate(payloads):
+                    flat = p["flat"].detach().reshape(-1)
+                    if flat.numel() != n:
+                        raise ValueError(f"flat payload has {flat.numel()} elements, expected {n}")
+                    self._slab.row_view(k, 0, n, torch.float32).copy_(
+                        flat.to(torch.float32), non_blocking=False)
+                ev = torch.cuda.Event()
+                ev.record(self._slab.copy_stream)
+            self._slab.last_copy = ev
+            self._slab.end_round()
+            ws = None
+            if K > ops.kchunk():
+                ws = torch.empty(n, dtype=torch.float32, device=self.device)
+            ops.weighted_mix(self._rows(K, 0), weights, self._flats["f32"],
+                             "sum_set" if first_round else "sum_add", acc_ws=ws, n=n)
+            out = self._download()
+            self._sync_model(self.model, out)
+            return out
 
     # -- streamed aggregation: fedavg_aggregator.py:406-497 ------------------------------------------
     def _aggregate_chunk(self, local_models, **kwargs) -> Dict:

@@ -546,14 +546,14 @@ __global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
         Pack<VEC> acc[VPT], g[VPT];
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
-            if (a.mode != FA_MIX_REPLACE) g[p] = load_state<VEC>(a.g, idx[p]);
+            if (a.mode != FA_MIX_REPLACE && a.mode != FA_MIX_SUM_SET) g[p] = load_state<VEC>(a.g, idx[p]);
             if (a.mode == FA_MIX_SUBTRACT) {
                 acc[p] = g[p];
             } else if (a.acc_in) {
                 acc[p] = load_state<VEC>(a.acc_in, idx[p]);
             } else {
                 // -0 + y == y for every y, so the single-arrival form adds x*w to nothing
-                const float zero = (a.mode == FA_MIX_CONVEX_ONE) ? -0.0f : 0.0f;
+                const float zero = (a.mode >= FA_MIX_CONVEX_ONE) ? -0.0f : 0.0f;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[p].e[j] = zero;
             }
@@ -593,6 +593,10 @@ __global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
                     float gt = g[p].e[j] * a.coeff;
                     acc[p].e[j] = gt + acc[p].e[j];
                 }
+            }
+            if (a.mode == FA_MIX_SUM_ADD && a.last) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[p].e[j] = g[p].e[j] + acc[p].e[j];
             }
             store_result(a.g, idx[p], acc[p], 1);
         }
@@ -1172,7 +1176,7 @@ int fa_server_opt_step(float* step, float* m, float* v, size_t n, int opt, doubl
 int fa_weighted_mix(const float* const* x, const double* w, int K, float* g, double coeff,
                     int mode, float* acc_ws, size_t n, fa_stream_t stream) {
     if (!x || !w || !g || K <= 0) return FA_ERR_INVALID;
-    if (mode < FA_MIX_REPLACE || mode > FA_MIX_CONVEX_ONE) return FA_ERR_INVALID;
+    if (mode < FA_MIX_REPLACE || mode > FA_MIX_SUM_SET) return FA_ERR_INVALID;
     if (mode == FA_MIX_CONVEX_ONE && K != 1) return FA_ERR_INVALID;
     if (K > FA_KCHUNK && mode != FA_MIX_SUBTRACT && !acc_ws) return FA_ERR_WORKSPACE;
     if (n == 0) return FA_OK;

@@ -129,7 +129,8 @@ def apply_step(g, step, n: Optional[int] = None) -> None:
                                    _stream(g)), "fa_apply_step")
 
 
-MIX_MODES = {"replace": 0, "convex": 1, "subtract": 2, "convex_one": 3}
+MIX_MODES = {"replace": 0, "convex": 1, "subtract": 2, "convex_one": 3, "sum_add": 4,
+             "sum_set": 5}
 
 
 def weighted_mix(x: Sequence, w: Sequence[float], g: torch.Tensor, mode: str, coeff: float = 0.0,

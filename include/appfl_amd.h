@@ -140,10 +140,16 @@ int fa_mean_i32(const int32_t* const* x, int K, int32_t* g, size_t n, fa_stream_
  *   FA_MIX_SUBTRACT: for k: g = g - x[k][i] * (float)w[k] (gradient_based form of both)
  *   FA_MIX_CONVEX_ONE (K = 1): g = g * (float)coeff + x[0][i] * (float)w[0]  -- FedCompass's
  *                    single arrival, which adds to no zero accumulator (sign of a zero result)
+ *   FA_MIX_SUM_ADD / FA_MIX_SUM_SET: acc = x[0]*w[0]; for k >= 1: acc = acc + x[k]*w[k];
+ *                    g = g + acc  /  g = acc -- the flat secure-aggregation payload path
+ *                    (algorithm/aggregator/fedavg_aggregator.py:180-217)
  * x, w: HOST arrays as in fa_reduce_opt.  acc_ws: n-float workspace, only needed when
  * K > FA_KCHUNK in the first two modes.
  */
-enum { FA_MIX_REPLACE = 0, FA_MIX_CONVEX = 1, FA_MIX_SUBTRACT = 2, FA_MIX_CONVEX_ONE = 3 };
+enum {
+    FA_MIX_REPLACE = 0, FA_MIX_CONVEX = 1, FA_MIX_SUBTRACT = 2, FA_MIX_CONVEX_ONE = 3,
+    FA_MIX_SUM_ADD = 4, FA_MIX_SUM_SET = 5
+};
 int fa_weighted_mix(const float* const* x, const double* w, int K, float* g, double coeff,
                     int mode, float* acc_ws, size_t n, fa_stream_t stream);
 

@@ -154,7 +154,33 @@ class OracleFedAvg(OracleBase):
                 self.global_state[key] = _int_div(s, len(local_models))
         return {k: self.global_state[k].copy() for k in chunk_keys}
 
+    def _aggregate_masked_flat(self, local_models):
+        """fedavg_aggregator.py:171-225: weighted sum of the clients' flat fp32 payloads, added
+        to the global state."""
+        payloads = list(local_models.values())
+        total = sum(p["num_examples"] for p in payloads)
+        acc = None
+        for p in payloads:
+            w = float(p["num_examples"]) / float(total) if self.client_weights_mode == "sample_size" \
+                else 1.0 / len(payloads)
+            term = to_np(p["flat"]).astype(F32, copy=False) * _f32(w)
+            acc = term if acc is None else acc + term
+        state, idx = {}, 0
+        for name, shp in payloads[0]["shapes"]:
+            num = int(np.prod(shp)) if len(shp) else 1
+            state[name] = acc[idx:idx + num].reshape(tuple(shp))
+            idx += num
+        if self.global_state is None:
+            self.global_state = {k: v.copy() for k, v in state.items()}
+        else:
+            for k, v in state.items():
+                self.global_state[k] = self.global_state[k] + v if k in self.global_state else v.copy()
+        return {k: v.copy() for k, v in self.global_state.items()}
+
     def aggregate(self, local_models, **kwargs):
+        if cfg_get(self.cfg, "use_secure_agg", False) and all(
+                isinstance(m, dict) and m.get("type") == "masked_update_flat" for m in local_models.values()):
+            return self._aggregate_masked_flat(local_models)
         local_models = {c: {k: to_np(v) for k, v in m.items()} for c, m in local_models.items()}
         if "_chunk_idx" in kwargs:
             return self._aggregate_chunk(local_models, **kwargs)

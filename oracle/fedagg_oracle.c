@@ -183,14 +183,20 @@ void or_mean_i32(const int32_t* const* x, int K, int32_t* g, size_t n) {
  * 3 (K = 1): g = g*coeff + x0*w0 with no zero accumulator (single FedCompass arrival). */
 int or_weighted_mix(const float* const* x, const double* w, int K, float* g, double coeff, int mode,
                     size_t n) {
-    if (K <= 0 || K > 65536 || mode < 0 || mode > 3 || (mode == 3 && K != 1)) return -1;
+    if (K <= 0 || K > 65536 || mode < 0 || mode > 5 || (mode == 3 && K != 1)) return -1;
     float wf[K];
     for (int k = 0; k < K; ++k) wf[k] = (float)w[k];
     const float c = (float)coeff;
     for (size_t i = 0; i < n; ++i) {
         float acc = (mode == 2) ? g[i] : 0.0f;
-        if (mode == 3) {
+        if (mode >= 3) {
+            /* modes 4 / 5 (fedavg_aggregator.py:180-217): first product assigned, rest added */
             acc = x[0][i] * wf[0];
+            for (int k = 1; k < K; ++k) {
+                float xw = x[k][i] * wf[k];
+                acc = acc + xw;
+            }
+            if (mode == 4) acc = g[i] + acc;
         } else {
             for (int k = 0; k < K; ++k) {
                 float xw = x[k][i] * wf[k];

@@ -260,8 +260,21 @@ def mix_scenarios() -> List[Dict]:
     return out
 
 
+def secure_scenarios() -> List[Dict]:
+    """Flat secure-aggregation payloads (fedavg_aggregator.py:171-225): every client sends the
+    flattened fp32 update plus its example count; the masks themselves are outside this path."""
+    out = []
+    for mode in ("equal", "sample_size"):
+        out.append({"id": f"FedAvg-secureflat-{mode}", "kind": "secure", "cls": "FedAvgAggregator",
+                    "spec": "toy", "model": False,
+                    "cfg": {"use_secure_agg": True, "client_weights_mode": mode},
+                    "rounds": [3, 2, 4], "sample_sizes": {}})
+    return out
+
+
 def all_scenarios() -> List[Dict]:
-    return sync_scenarios() + async_scenarios() + chunked_scenarios() + mix_scenarios()
+    return (sync_scenarios() + async_scenarios() + chunked_scenarios() + mix_scenarios()
+            + secure_scenarios())
 
 
 def _state_snapshots(agg) -> List[Tuple[str, Dict]]:
@@ -305,6 +318,18 @@ def run_scenario(factory: Callable, sc: Dict) -> List[Tuple[str, Dict[str, np.nd
             for lbl, d in _state_snapshots(agg):
                 rec.append((f"round{r}.{lbl}", d))
             rec.append((f"round{r}", _snap(out)))
+        rec.append(("final_get_parameters", _snap(agg.get_parameters())))
+    elif sc["kind"] == "secure":
+        names = [n for n, (_, kind) in spec.items() if kind == "f32"]
+        for r, K in enumerate(sc["rounds"]):
+            local = {}
+            for c in range(K):
+                st = make_state(spec, seed=6000 + 31 * r + c, gradient=True, scale=0.01)
+                flat = torch.cat([st[n].reshape(-1) for n in names])
+                local[c] = {"type": "masked_update_flat", "flat": flat,
+                            "shapes": [(n, tuple(st[n].shape)) for n in names],
+                            "num_examples": 10 + 7 * c + r}
+            rec.append((f"round{r}", _snap(agg.aggregate(local))))
         rec.append(("final_get_parameters", _snap(agg.get_parameters())))
     elif sc["kind"] == "compass":
         gb = sc["cfg"].get("gradient_based", False)
