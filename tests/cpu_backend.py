@@ -43,3 +43,8 @@ def server_opt_step(step, m, v, opt, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0, n=No
 def apply_step(g, step, n=None):
     n = g.numel() if n is None else n
     OC.apply_step(_np(g, n), _np(step, n))
+
+
+def mean(x, g, n=None):
+    n = g.numel() if n is None else n
+    OC.mean([np.ascontiguousarray(_np(t, n)) for t in x], _np(g, n))

@@ -87,3 +87,48 @@ def test_shard_bounds_cover_the_vector():
             assert spans[0][0] == 0 and spans[-1][1] == n
             for (a, b), (c, d) in zip(spans, spans[1:]):
                 assert b == c and a <= b and c <= d
+
+
+def _sd_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size")
+        agg = ShardedFedAvgAggregator(S.ToyModel(), cfg, None, algorithm="FedAdam", device="cpu",
+                                      backend=cpu_backend)
+        for c in range(5):
+            agg.set_client_sample_size(c, 4 + 3 * c)
+        recs = []
+        for r, K in enumerate([2, 5, 3]):
+            local = {c: S.make_state(S.TOY, seed=700 + 10 * r + c) for c in range(K)}
+            if r == 1:
+                del local[2]["fc.weight"]            # a client lacking a weighted entry
+            recs.append({k: v.numpy().copy() for k, v in agg.aggregate(local).items()})
+        if rank == 1:                                   # every rank holds the whole result
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_state_dict_aggregator_matches_single_process_oracle(tmp_path):
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_sd_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out, allow_pickle=True)
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size")
+    ora = OA.OracleFedAdam(S.ToyModel(), cfg, None)
+    for c in range(5):
+        ora.set_client_sample_size(c, 4 + 3 * c)
+    for r, K in enumerate([2, 5, 3]):
+        local = {c: S.make_state(S.TOY, seed=700 + 10 * r + c) for c in range(K)}
+        if r == 1:
+            del local[2]["fc.weight"]
+        want = ora.aggregate(local)
+        assert list(got[r]) == list(want)
+        for k in want:
+            assert got[r][k].dtype == want[k].dtype and got[r][k].shape == want[k].shape, k
+            assert got[r][k].tobytes() == want[k].tobytes(), (r, k)

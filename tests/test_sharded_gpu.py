@@ -3,6 +3,8 @@ the plain fused round), complementing the 2-rank gloo rehearsal."""
 
 import numpy as np
 import pytest
+
+import golden_util
 import torch
 
 from oracle import c_oracle as OC
@@ -31,3 +33,22 @@ def test_single_rank_modes_match_oracle(mode):
             agg.round_whole(dx, w)
     got = agg.all_gather_global().cpu().numpy()[:n]
     assert np.array_equal(got.view(np.uint32), g.view(np.uint32))
+
+
+def test_state_dict_sharded_aggregator_single_rank_matches_plain_aggregator():
+    import scenarios as S
+    import appfl_amd.aggregator as A
+    from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+    cfg = dict(S.HP["FedYogiAggregator"], client_weights_mode="sample_size")
+    plain = A.FedYogiAggregator(S.ToyModel(), cfg, None)
+    shard = ShardedFedAvgAggregator(S.ToyModel(), cfg, None, algorithm="FedYogi")
+    for agg in (plain, shard):
+        for c in range(4):
+            agg.set_client_sample_size(c, 5 + 2 * c)
+    for r, K in enumerate([3, 4, 2]):
+        local = {c: S.make_state(S.TOY, seed=900 + 10 * r + c) for c in range(K)}
+        want = plain.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
+        got = shard.aggregate(local)
+        assert list(got) == list(want)
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (r, k)
