@@ -223,6 +223,18 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._slab.upload(row, local_model, fill_missing_from=self._flats["f32"])
             self._prestaged[client_id] = (row, local_model)
 
+    def stage_bytes(self, client_id, model_bytes) -> Dict:
+        """`stage` for an update still in wire form (`torch.save` bytes, comm/mpi/serializer.py:46-50,
+        comm/grpc/utils.py:20-24): the tensors are read in place from `model_bytes` and packed
+        straight into the pinned staging row, skipping the per-tensor CPU copies `torch.load`
+        makes (agent/server.py:505-513).  Returns the state dict of views to hand to the
+        scheduler / `aggregate` in place of the deserialised model."""
+        from .. import wire
+
+        local_model = wire.bytes_to_model(model_bytes)
+        self.stage(client_id, local_model)
+        return local_model
+
     def _stage(self, local_models) -> None:
         """Pack and upload every client's state dict into the device slab (client order =
         dict order = arrival order, which is the reduction order); clients already uploaded by

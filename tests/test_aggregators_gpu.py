@@ -174,3 +174,24 @@ def test_staging_on_arrival_gives_the_same_round():
         got = staged.aggregate(models)
         for k in want:
             assert torch.equal(got[k], want[k]), (r, k)
+
+
+def test_stage_bytes_reads_the_wire_buffer_in_place():
+    """Updates handed over as torch.save bytes (what the communicators receive) give the same
+    round as deserialised state dicts."""
+    import io
+
+    import appfl_amd.aggregator as A
+    cfg = dict(S.HP["FedYogiAggregator"], client_weights_mode="equal")
+    plain, wired = A.FedYogiAggregator(None, cfg, None), A.FedYogiAggregator(None, cfg, None)
+    for r in range(2):
+        models = {c: S.make_state(S.RAGGED, seed=70 * r + c) for c in range(4)}
+        want = plain.aggregate(models)
+        views = {}
+        for c, m in models.items():
+            buf = io.BytesIO()
+            torch.save(m, buf)
+            views[c] = wired.stage_bytes(c, buf.getvalue())
+        got = wired.aggregate(views)
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (r, k)
