@@ -823,13 +823,17 @@ int launch_reduce_u(const ReduceArgs& a, hipStream_t st) {
     }
 }
 
+// Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.
+bool takes_stash_path(int K, uint64_t nvec) {
+    return (g_shape.stash < 0 && K > kStashUnroll) ||
+           (g_shape.stash > 0 && K >= kStashMinClients &&
+            nvec >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile);
+}
+
 template <int OPT, int VEC>
 int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
     if (VEC == 1) return launch_reduce_s<OPT, 1, 1, 8, true>(a, st);
-    if ((g_shape.stash < 0 && a.K > kStashUnroll) ||
-        (g_shape.stash > 0 && a.K >= kStashMinClients &&
-         a.n >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile))
-        return launch_stash<OPT>(a, st);
+    if (takes_stash_path(a.K, a.n)) return launch_stash<OPT>(a, st);
     switch (g_shape.vpt) {
         case 1: return launch_reduce_u<OPT, 1>(a, st);
         case 4: return launch_reduce_u<OPT, 4>(a, st);
@@ -1071,6 +1075,12 @@ extern "C" {
 int fa_version(void) { return 100; }
 
 int fa_kchunk(void) { return FA_KCHUNK; }
+
+const char* fa_reduce_kernel_name(int K, size_t n) {
+    const int k = K > FA_KCHUNK ? FA_KCHUNK : K;
+    const uint64_t seg = n > kSegment ? kSegment : n;
+    return takes_stash_path(k, seg / 4) ? "reduce_stash_kernel" : "reduce_kernel";
+}
 
 int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash) {
     if (vpt != 1 && vpt != 2 && vpt != 4) return FA_ERR_INVALID;
