@@ -62,10 +62,12 @@ int fa_kchunk(void);
 const char* fa_reduce_kernel_name(int K, size_t n);
 /*
  * Benchmark hook (no counterpart in the reference): selects the launch shape of the 128-bit
- * reduce kernel -- vectors per thread (1|2|4), clients loaded ahead (4|8|16), nt (bit 0:
- * non-temporal client loads, bit 1: plain instead of write-through result stores), grid cap (<= 0: default) of the tile-per-block kernel, and from how many
- * 16-KiB tiles per CU on a vector takes the persistent kernel that parks results in LDS and
- * writes them in bursts (stash: 0 never, < 0 always, default 4).  Results do not depend on it.
+ * reduce kernels -- vectors per thread (1|2|4), clients loaded ahead (4|8|16), nt (bit 0:
+ * non-temporal client loads, bit 1: plain instead of write-through result stores, bit 2: the
+ * persistent kernel gives each block one contiguous range instead of every gridDim-th tile),
+ * grid cap (<= 0: default) of the tile-per-block kernel, and from how many 16-KiB tiles per CU
+ * on a launch of >= 16 clients takes the persistent kernel that parks results in LDS and writes
+ * them in bursts (stash: 0 never, < 0 always, default 2).  Results do not depend on it.
  * Process-wide; not synchronised with concurrent calls.
  */
 int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);

@@ -274,12 +274,16 @@ def test_every_launch_shape_gives_the_same_bits():
 
 @pytest.mark.parametrize("opt,hp", [("none", {}), ("avgm", HP), ("adam", HP), ("yogi", HP_YOGI), ("adagrad", HP)])
 @pytest.mark.parametrize("n", [7, 1027, 300007, 4500003])
-def test_persistent_stash_kernel_matches_oracle(opt, hp, n):
+@pytest.mark.parametrize("nt", [1, 5], ids=["round_robin", "contiguous"])
+def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
     """The persistent LDS-stash kernel forced on (also for vectors far smaller than its grid, so
-    most blocks own an empty or partial range) and at its natural size: same bits as the oracle
-    for the final state, the optional step output and the step-only mode."""
+    most blocks own no or a partial tile) and at its natural size, with both ways of dealing
+    tiles to blocks: same bits as the oracle for the final state, the optional step output and
+    the step-only mode."""
     from appfl_amd import ops
-    K = 5 if n > 1000000 else 11
+    K = 17 if n > 1000000 else 11
+    if n > 1000000:
+        assert ops.reduce_kernel_name(K, n) == "reduce_stash_kernel"
     code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI,
             "adagrad": O.OPT_ADAGRAD}[opt]
     base, xs = make_clients(n, K)
@@ -292,7 +296,7 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n):
     O.reduce_opt(xs, w, g_ref, m_ref, v_ref, code, step_out=step_ref, **hp)
     dx = [dev(x) for x in xs]
     try:
-        ops.tune(stash=-1)
+        ops.tune(nt=nt, stash=-1)
         for with_step in (False, True):
             g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, v_ref.flat[0] * 0 + (
                 np.float32(0.0 if opt in ("none", "avgm") else hp["tau"] ** 2))))
