@@ -327,14 +327,22 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
     const unsigned u1 = static_cast<unsigned>(static_cast<uint64_t>(units) * (blockIdx.x + 1) / gridDim.x);
     unsigned r0 = u0 * 64u;
     unsigned r1 = (u1 * 64u < a.n) ? u1 * 64u : a.n;
-    unsigned ntiles, tstride = kStashTile;
+    unsigned ntiles, tstride = kStashTile, tlen = kStashTile;
     if (a.il) {
-        const unsigned total = (a.n + kStashTile - 1) / kStashTile;
+        // Every block gets the same number of equally long tiles where that is possible: the
+        // tile is shortened, in steps of one wave-row (64 vectors = 1 KiB; finer steps cost
+        // more in misaligned wave loads than they balance), so that the last round is as full
+        // as the others; lanes past the tile's end idle.
+        const unsigned per_round = gridDim.x * kStashTile;
+        const unsigned rounds = (a.n + per_round - 1) / per_round;
+        const unsigned slots = gridDim.x * rounds;
+        tlen = (((a.n + slots - 1) / slots) + 63u) & ~63u;
+        const unsigned total = (a.n + tlen - 1) / tlen;
         if (blockIdx.x >= total) return;
         ntiles = (total - blockIdx.x + gridDim.x - 1) / gridDim.x;
-        r0 = blockIdx.x * kStashTile;
+        r0 = blockIdx.x * tlen;
         r1 = a.n;
-        tstride = gridDim.x * kStashTile;
+        tstride = gridDim.x * tlen;
     } else {
         if (r0 >= r1) return;
         ntiles = (r1 - r0 + kStashTile - 1) / kStashTile;
@@ -360,8 +368,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
     int ib = 0, cb = 0;        // client set within that tile
 
     auto vec_index = [&](unsigned tile, int p) -> unsigned {
-        const unsigned i = r0 + tile * tstride + p * kThreads + threadIdx.x;
-        return i < r1 ? i : r1 - 1;   // threads past the range redo the last vector, never store
+        const unsigned off = p * kThreads + threadIdx.x;
+        const unsigned i = r0 + tile * tstride + off;
+        return (off < tlen && i < r1) ? i : r1 - 1;   // idle lanes redo the last vector, never store
     };
     auto issue = [&](Pack<4> (&x)[U][VPT]) {
         if (it >= ntiles) return;
@@ -428,8 +437,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
                 for (int c = 0; c < NV; ++c)
 #pragma unroll
                     for (int p = 0; p < VPT; ++p) {
-                        const unsigned i = r0 + (first + jj) * tstride + p * kThreads + threadIdx.x;
-                        if (i < r1) burst_store(dst[c], nbytes, i, stash[jj][c][p][threadIdx.x]);
+                        const unsigned off = p * kThreads + threadIdx.x;
+                        const unsigned i = r0 + (first + jj) * tstride + off;
+                        if (off < tlen && i < r1) burst_store(dst[c], nbytes, i, stash[jj][c][p][threadIdx.x]);
                     }
             }
         }
