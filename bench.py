@@ -47,6 +47,8 @@ def parse():
                     help="also time the round followed by an all-gather of the updated shards")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU time budget of each cpu_baseline leg")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time aggregate() from CPU state dicts to a CPU state dict (PCIe included)")
     return ap.parse_args()
 
 
@@ -224,6 +226,60 @@ def cpu_baseline(wl, budget_s):
     return naive_out, fused_out
 
 
+def end_to_end(wl, rounds=4):
+    """aggregate() of the drop-in class as the scheduler calls it: K CPU state dicts in, one CPU
+    state dict out (pack + pinned H2D of every client, kernels, D2H).  PCIe-inclusive; reported
+    beside `value`, never as `value`."""
+    import appfl_amd.aggregator as A
+    from appfl_amd import ops, workloads as W
+
+    rows, K = wl["table"](), wl["K"]
+    nf = W.numel([r for r in rows if r[2] == torch.float32])
+    base = torch.empty(nf, dtype=torch.float32, device="cuda")
+    ops.synth_fill(base, 7, scale=0.05)
+    buf = torch.empty_like(base)
+
+    def state(seed):
+        if seed is None:
+            flat = base.cpu()
+        else:
+            ops.synth_fill(buf, seed, scale=0.01, base=base)
+            flat = buf.cpu()
+        out, off = {}, 0
+        for name, shape, dtype, _ in rows:
+            n = 1
+            for d in shape:
+                n *= d
+            if dtype == torch.float32:
+                out[name] = flat[off:off + n].view(shape).clone()
+                off += n
+            else:
+                out[name] = torch.full(shape, 3, dtype=dtype)
+        return out
+
+    clients = {k: state(1000 + k) for k in range(K)}
+    nbytes = sum(t.numel() * t.element_size() for t in clients[0].values())
+    del base, buf
+    agg = getattr(A, wl["cls"])(None, dict(W.EXAMPLE_CONFIGS[wl["cls"]]), None)
+    ts = []
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        agg.aggregate(clients)
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts[1:])[len(ts[1:]) // 2]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    agg._stage(clients)
+    torch.cuda.synchronize()
+    t_stage = time.perf_counter() - t0
+    return {"value": round(K * nbytes / t / 1e9, 2), "unit": "GB/s", "ms_per_round": round(t * 1e3, 2),
+            "first_round_ms": round(ts[0] * 1e3, 2), "stage_ms": round(t_stage * 1e3, 2),
+            "stage_GBps": round(K * nbytes / t_stage / 1e9, 2),
+            "what": f"aggregate() of {K} CPU state dicts ({nbytes} B each) -> CPU state dict, "
+                    "median of rounds 2.."}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -320,6 +376,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(b.alg_bytes)},
         }
         out.update(extra)
+        if world == 1 and a.end_to_end and not is_async:
+            out["end_to_end"] = end_to_end(wl)
         if world == 1 and not a.no_cpu_baseline:
             del b
             torch.cuda.empty_cache()
