@@ -103,7 +103,8 @@ __device__ __forceinline__ void store_result(float* p, unsigned i, const Pack<4>
     if (wt) {
         f4 t;
         t.x = r.e[0]; t.y = r.e[1]; t.z = r.e[2]; t.w = r.e[3];
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7FFFFFFF, 0x00020000);
+        // 4 GiB window: a launch addresses at most kSegment floats = 2 GiB from p
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, -1, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, t), rs, i * 16u, 0, 17);
     } else {
         store_state<4>(p, i, r);

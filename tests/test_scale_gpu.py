@@ -165,3 +165,66 @@ def test_config5_flat_162m_k32_shard():
         base_w = O.synth_fill(b - a, BASE_SEED, first=a, scale=0.05)
         O.reduce_opt(_host_rows(a, b, seeds, base_w), w, base_w)
         _same(g, a, b, base_w, "g")
+
+
+@pytest.mark.parametrize("K", [2, 17], ids=["tile_kernel", "persistent_kernel"])
+def test_vector_longer_than_one_launch_segment(K):
+    """More than 2^29 elements: the library cuts the axis into segments of 2 GiB per launch;
+    the seam and both ends must come out like everything else."""
+    n = (1 << 29) + 70_003
+    free, _ = torch.cuda.mem_get_info()
+    if free < (K + 4) * n * 4 + (1 << 30):
+        pytest.skip("not enough free device memory")
+    w = [(1.0 + k) / sum(1.0 + j for j in range(K)) for k in range(K)]
+    seeds = [6000 + k for k in range(K)]
+    base = torch.empty(n, dtype=torch.float32, device="cuda")
+    ops.synth_fill(base, BASE_SEED, scale=0.05)
+    slab = _device_rows(K, n, seeds, base)
+    g, m = base.clone(), torch.zeros_like(base)
+    v = torch.full_like(base, float(np.float32(HP_ADAM["tau"] ** 2)))
+    ops.reduce_opt([slab[k] for k in range(K)], w, g, m, v, "adam", n=n, **HP_ADAM)
+    torch.cuda.synchronize()
+    seam = 1 << 29
+    L = 1 << 15
+    wins = _windows(n, 8, L) + [(seam - L, seam), (seam - 5, seam + L), (seam, seam + L)]
+    for a, b in wins:
+        base_w = O.synth_fill(b - a, BASE_SEED, first=a, scale=0.05)
+        gw, mw = base_w.copy(), np.zeros_like(base_w)
+        vw = np.full_like(base_w, np.float32(HP_ADAM["tau"] ** 2))
+        O.reduce_opt(_host_rows(a, b, seeds, base_w), w, gw, mw, vw, O.OPT_ADAM, **HP_ADAM)
+        _same(g, a, b, gw, "g")
+        _same(m, a, b, mw, "m")
+        _same(v, a, b, vw, "v")
+
+
+def test_other_entry_points_across_the_segment_seam():
+    n = (1 << 29) + 70_003
+    free, _ = torch.cuda.mem_get_info()
+    if free < 8 * n * 4:
+        pytest.skip("not enough free device memory")
+    K, seeds = 3, [6100, 6101, 6102]
+    w = [0.2, 0.3, 0.1]
+    base = torch.empty(n, dtype=torch.float32, device="cuda")
+    ops.synth_fill(base, BASE_SEED, scale=0.05)
+    slab = _device_rows(K, n, seeds, base)
+    rows = [slab[k] for k in range(K)]
+    g_async = base.clone()
+    ops.async_mix(rows[0], 0.05, g_async)
+    g_mix = base.clone()
+    ops.weighted_mix(rows, w, g_mix, "convex", coeff=0.4)
+    g_mean = torch.empty_like(base)
+    ops.mean(rows, g_mean)
+    torch.cuda.synchronize()
+    seam, L = 1 << 29, 1 << 14
+    for a, b in [(0, L), (seam - L, seam + L), (n - L - 3, n)]:
+        base_w = O.synth_fill(b - a, BASE_SEED, first=a, scale=0.05)
+        xs = _host_rows(a, b, seeds, base_w)
+        want = base_w.copy()
+        O.async_mix(xs[0], 0.05, False, True, want)
+        _same(g_async, a, b, want, "async_mix")
+        want = base_w.copy()
+        O.weighted_mix(xs, w, want, 1, 0.4)
+        _same(g_mix, a, b, want, "weighted_mix")
+        want = np.empty_like(base_w)
+        O.mean(xs, want)
+        _same(g_mean, a, b, want, "mean")
