@@ -655,41 +655,87 @@ __device__ __forceinline__ float async_step(float x, float g, float alpha) {
     return alpha * nx;
 }
 
+// The arrival kernels move 2-3 streams in and 1-2 out per element and nothing else; each thread
+// keeps kArrivalVpt vectors of every input stream in flight and results leave write-through.
+constexpr int kArrivalVpt = 4;
+
+template <int VEC>
+__device__ __forceinline__ void arrival_indices(unsigned t, unsigned n, unsigned (&idx)[VEC == 4 ? kArrivalVpt : 1],
+                                                bool (&ok)[VEC == 4 ? kArrivalVpt : 1]) {
+    constexpr int VPT = VEC == 4 ? kArrivalVpt : 1;
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+        const unsigned i = t * (kThreads * VPT) + p * kThreads + threadIdx.x;
+        ok[p] = i < n;
+        idx[p] = ok[p] ? i : n - 1;
+    }
+}
+
 template <int VEC, int MODE>
 __global__ __launch_bounds__(kThreads) void async_mix_kernel(const float* x, float alpha, float* g,
-                                                           float* step_out, unsigned n) {
-    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-        Pack<VEC> xv = load_stream<VEC>(x, i), gv = load_state<VEC>(g, i), sv;
+                                                           float* step_out, unsigned n, int wt) {
+    constexpr int VPT = VEC == 4 ? kArrivalVpt : 1;
+    const unsigned tiles = (n + kThreads * VPT - 1) / (kThreads * VPT);
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+        unsigned idx[VPT];
+        bool ok[VPT];
+        arrival_indices<VEC>(t, n, idx, ok);
+        Pack<VEC> xv[VPT], gv[VPT], sv[VPT];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            sv.e[j] = async_step<MODE>(xv.e[j], gv.e[j], alpha);
-            gv.e[j] = gv.e[j] + sv.e[j];
+        for (int p = 0; p < VPT; ++p) {
+            xv[p] = load_stream<VEC>(x, idx[p]);
+            gv[p] = load_state<VEC>(g, idx[p]);
         }
-        if (step_out) store_state<VEC>(step_out, i, sv);
-        store_state<VEC>(g, i, gv);
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                sv[p].e[j] = async_step<MODE>(xv[p].e[j], gv[p].e[j], alpha);
+                gv[p].e[j] = gv[p].e[j] + sv[p].e[j];
+            }
+            if (ok[p]) {
+                if (step_out) store_result(step_out, idx[p], sv[p], wt);
+                store_result(g, idx[p], gv[p], wt);
+            }
+        }
     }
 }
 
 // FLUSH: also g = g + step after the accumulate.
 template <int VEC, int MODE, bool FLUSH>
 __global__ __launch_bounds__(kThreads) void buff_accum_kernel(const float* x, float alpha, float* g,
-                                                            float* step, int first, unsigned n) {
-    for (unsigned i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-        Pack<VEC> xv = load_stream<VEC>(x, i), gv = load_state<VEC>(g, i), sv;
-        if (first) {
+                                                            float* step, int first, unsigned n, int wt) {
+    constexpr int VPT = VEC == 4 ? kArrivalVpt : 1;
+    const unsigned tiles = (n + kThreads * VPT - 1) / (kThreads * VPT);
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+        unsigned idx[VPT];
+        bool ok[VPT];
+        arrival_indices<VEC>(t, n, idx, ok);
+        Pack<VEC> xv[VPT], gv[VPT], sv[VPT];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) sv.e[j] = 0.0f;
-        } else {
-            sv = load_state<VEC>(step, i);
+        for (int p = 0; p < VPT; ++p) {
+            xv[p] = load_stream<VEC>(x, idx[p]);
+            gv[p] = load_state<VEC>(g, idx[p]);
+            if (first) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) sv[p].e[j] = 0.0f;
+            } else {
+                sv[p] = load_state<VEC>(step, idx[p]);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            float t = async_step<MODE>(xv.e[j], gv.e[j], alpha);
-            sv.e[j] = sv.e[j] + t;
-            if (FLUSH) gv.e[j] = gv.e[j] + sv.e[j];
+        for (int p = 0; p < VPT; ++p) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float d = async_step<MODE>(xv[p].e[j], gv[p].e[j], alpha);
+                sv[p].e[j] = sv[p].e[j] + d;
+                if (FLUSH) gv[p].e[j] = gv[p].e[j] + sv[p].e[j];
+            }
+            if (ok[p]) {
+                store_result(step, idx[p], sv[p], wt);
+                if (FLUSH) store_result(g, idx[p], gv[p], wt);
+            }
         }
-        store_state<VEC>(step, i, sv);
-        if (FLUSH) store_state<VEC>(g, i, gv);
     }
 }
 
@@ -1050,17 +1096,24 @@ int flush_mean_dispatch(T* g, const T* step, int K, size_t n, hipStream_t st) {
     return FA_OK;
 }
 
+// Grid of the 128-bit arrival kernels: one block per tile of kArrivalVpt vectors per thread.
+unsigned arrival_grid(size_t nvec) {
+    size_t tiles = (nvec + kThreads * kArrivalVpt - 1) / (kThreads * kArrivalVpt);
+    size_t cap = static_cast<size_t>(g_shape.max_blocks > 0 ? g_shape.max_blocks : kMaxBlocks);
+    return static_cast<unsigned>(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+}
+
 template <int MODE>
 int async_mix_mode(const float* x, float alpha, float* g, float* step_out, size_t n, bool a16,
                    hipStream_t st) {
     return for_each_range(n, a16, [&](size_t off, size_t cnt, bool vec) {
         float* so = step_out ? step_out + off : nullptr;
         if (vec)
-            hipLaunchKernelGGL((async_mix_kernel<4, MODE>), dim3(grid_for(cnt)), dim3(kThreads), 0,
-                               st, x + off, alpha, g + off, so, static_cast<unsigned>(cnt));
+            hipLaunchKernelGGL((async_mix_kernel<4, MODE>), dim3(arrival_grid(cnt)), dim3(kThreads), 0,
+                               st, x + off, alpha, g + off, so, static_cast<unsigned>(cnt), g_write_through);
         else
             hipLaunchKernelGGL((async_mix_kernel<1, MODE>), dim3(grid_for(cnt)), dim3(kThreads), 0,
-                               st, x + off, alpha, g + off, so, static_cast<unsigned>(cnt));
+                               st, x + off, alpha, g + off, so, static_cast<unsigned>(cnt), 0);
         return launch_status();
     });
 }
@@ -1070,13 +1123,13 @@ int buff_accum_mode(const float* x, float alpha, float* g, float* step, int firs
                     bool a16, hipStream_t st) {
     return for_each_range(n, a16, [&](size_t off, size_t cnt, bool vec) {
         if (vec)
-            hipLaunchKernelGGL((buff_accum_kernel<4, MODE, FLUSH>), dim3(grid_for(cnt)),
+            hipLaunchKernelGGL((buff_accum_kernel<4, MODE, FLUSH>), dim3(arrival_grid(cnt)),
                                dim3(kThreads), 0, st, x + off, alpha, g + off, step + off, first,
-                               static_cast<unsigned>(cnt));
+                               static_cast<unsigned>(cnt), g_write_through);
         else
             hipLaunchKernelGGL((buff_accum_kernel<1, MODE, FLUSH>), dim3(grid_for(cnt)),
                                dim3(kThreads), 0, st, x + off, alpha, g + off, step + off, first,
-                               static_cast<unsigned>(cnt));
+                               static_cast<unsigned>(cnt), 0);
         return launch_status();
     });
 }
