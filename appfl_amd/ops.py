@@ -61,7 +61,7 @@ def reduce_kernel_name(K: int, n: int) -> str:
     return N.load().fa_reduce_kernel_name(K, n).decode()
 
 
-def tune(vpt: int = 4, unroll: int = 8, nt: int = 1, max_blocks: int = 0, stash: int = 2) -> None:
+def tune(vpt: int = 0, unroll: int = 8, nt: int = 1, max_blocks: int = 0, stash: int = 2) -> None:
     N.check(N.load().fa_tune(vpt, unroll, nt, max_blocks, stash), "fa_tune")
 
 

@@ -62,7 +62,8 @@ int fa_kchunk(void);
 const char* fa_reduce_kernel_name(int K, size_t n);
 /*
  * Benchmark hook (no counterpart in the reference): selects the launch shape of the 128-bit
- * reduce kernels -- vectors per thread (1|2|4), clients loaded ahead (4|8|16), nt (bit 0:
+ * reduce kernels -- vectors per thread (1|2|4; 0 = chosen per call, the default), clients
+ * loaded ahead (4|8|16; ignored when vectors per thread is 0), nt (bit 0:
  * non-temporal client loads, bit 1: plain instead of write-through result stores, bit 2: the
  * persistent kernel gives each block one contiguous range instead of every gridDim-th tile),
  * grid cap (<= 0: default) of the tile-per-block kernel, and from how many 16-KiB tiles per CU
