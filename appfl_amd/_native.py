@@ -30,7 +30,7 @@ SIGNATURES = {
     "fa_version": (_i, []),
     "fa_error_string": (C.c_char_p, [_i]),
     "fa_kchunk": (_i, []),
-    "fa_reduce_kernel_name": (C.c_char_p, [_i, _sz]),
+    "fa_reduce_kernel_name": (C.c_char_p, [_i, _sz, _i]),
     "fa_tune": (_i, [_i, _i, _i, _i, _i]),
     "fa_reduce_opt": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),
     "fa_reduce_apply": (_i, [_p, _p, _i, _p, _sz, _p, _p]),

@@ -896,25 +896,31 @@ int launch_reduce_u(const ReduceArgs& a, int unroll, hipStream_t st) {
     }
 }
 
-// Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.
-bool takes_stash_path(int K, uint64_t nvec) {
-    return (g_shape.stash < 0 && K > kStashUnroll) ||
-           (g_shape.stash > 0 && K >= kStashMinClients &&
-            nvec >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile);
+// Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.  The
+// optimizers with two moment vectors stay on the tile-per-block kernel up to ~100 clients: with
+// four result vectors per tile the LDS budget holds only three tiles per burst, and many
+// resident waves hide their six state streams better than one wave per SIMD (measured 2-5 %
+// faster at K = 16..64, 2 % slower at K = 100).
+constexpr int kStashMinClientsTwoMoments = 96;
+bool takes_stash_path(int opt, int K, uint64_t nvec) {
+    if (g_shape.stash < 0) return K > kStashUnroll;
+    const int kmin = opt >= FA_OPT_ADAM ? kStashMinClientsTwoMoments : kStashMinClients;
+    return g_shape.stash > 0 && K >= kmin &&
+           nvec >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile;
 }
 
 template <int OPT, int VEC>
 int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
     if (VEC == 1) return launch_reduce_s<OPT, 1, 1, 8, true>(a, st);
-    if (takes_stash_path(a.K, a.n)) return launch_stash<OPT>(a, st);
+    if (takes_stash_path(OPT, a.K, a.n)) return launch_stash<OPT>(a, st);
     int vpt = g_shape.vpt, unroll = g_shape.unroll;
     if (vpt == 0) {
-        // Few clients on a long vector: one vector per thread and 16 clients ahead keeps more
-        // waves resident to cover the optimizer epilogue (measured +10-20 % for the two-moment
-        // optimizers, +2-4 % for plain FedAvg at K = 2..15); short vectors are launch bound and
-        // do better with fewer, fatter blocks.
+        // Long vectors: few vectors per thread and 16 clients ahead keep more waves resident to
+        // cover the state streams and the optimizer epilogue (measured +10-20 % for the
+        // two-moment optimizers, +2-4 % for plain FedAvg at K = 2..15); short vectors are launch
+        // bound and do better with fewer, fatter blocks.
         const bool lean = a.n >= kLeanTileVectors;
-        vpt = lean ? 1 : 4;
+        vpt = !lean ? 4 : (a.K >= kStashMinClients ? 2 : 1);
         unroll = lean ? 16 : 8;
     }
     switch (vpt) {
@@ -1167,10 +1173,10 @@ int fa_version(void) { return 100; }
 
 int fa_kchunk(void) { return FA_KCHUNK; }
 
-const char* fa_reduce_kernel_name(int K, size_t n) {
+const char* fa_reduce_kernel_name(int K, size_t n, int opt) {
     const int k = K > FA_KCHUNK ? FA_KCHUNK : K;
     const uint64_t seg = n > kSegment ? kSegment : n;
-    return takes_stash_path(k, seg / 4) ? "reduce_stash_kernel" : "reduce_kernel";
+    return takes_stash_path(opt, k, seg / 4) ? "reduce_stash_kernel" : "reduce_kernel";
 }
 
 int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash) {

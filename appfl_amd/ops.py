@@ -57,8 +57,8 @@ def kchunk() -> int:
     return N.load().fa_kchunk()
 
 
-def reduce_kernel_name(K: int, n: int) -> str:
-    return N.load().fa_reduce_kernel_name(K, n).decode()
+def reduce_kernel_name(K: int, n: int, opt: str = "none") -> str:
+    return N.load().fa_reduce_kernel_name(K, n, OPT_CODES[opt]).decode()
 
 
 def tune(vpt: int = 0, unroll: int = 8, nt: int = 1, max_blocks: int = 0, stash: int = 2) -> None:

@@ -81,7 +81,7 @@ class SyncBench:
                            scale=0.01, base=g, n=lay.n_f32)
         self.weights = [1.0 / self.K] * self.K
         self.opt = self.agg._OPT
-        self.kernel = "%s<%s>" % (ops.reduce_kernel_name(self.K, self.n_step), self.opt)
+        self.kernel = "%s<%s>" % (ops.reduce_kernel_name(self.K, self.n_step, self.opt), self.opt)
         self.alg_bytes = 4 * (self.K + STATE_VECTORS[self.opt]) * self.n_step
         self.client_bytes = self.K * self.payload
         self.result_numel = lay.n_f32

@@ -57,9 +57,9 @@ const char* fa_error_string(int code);
 /* Number of clients one launch folds (FA_KCHUNK), for hosts that size workspaces. */
 int fa_kchunk(void);
 /* Name of the device kernel fa_reduce_opt launches for K clients of n 16-byte-aligned fp32
- * elements on the current device (profilers list it under this name); no counterpart in the
- * reference. */
-const char* fa_reduce_kernel_name(int K, size_t n);
+ * elements and optimizer `opt` (FA_OPT_*) on the current device (profilers list it under this
+ * name); no counterpart in the reference. */
+const char* fa_reduce_kernel_name(int K, size_t n, int opt);
 /*
  * Benchmark hook (no counterpart in the reference): selects the launch shape of the 128-bit
  * reduce kernels -- vectors per thread (1|2|4; 0 = chosen per call, the default), clients

@@ -283,7 +283,8 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
     from appfl_amd import ops
     K = 17 if n > 1000000 else 11
     if n > 1000000:
-        assert ops.reduce_kernel_name(K, n) == "reduce_stash_kernel"
+        assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
+        assert ops.reduce_kernel_name(K, n, "adam") == "reduce_kernel"
     code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI,
             "adagrad": O.OPT_ADAGRAD}[opt]
     base, xs = make_clients(n, K)
