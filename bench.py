@@ -117,8 +117,9 @@ class AsyncBench:
         self.K = wl["K"]
         self.i = 0
         self.kernel = "buff_accum_kernel" if self.buff else "async_mix_kernel"
-        # x, g read + g write; FedBuff: x, g, step read + step write (+ g write on the flush)
-        self.alg_bytes = (16 * self.n_step + 4 * self.n_step / self.K) if self.buff else 12 * self.n_step
+        # x, g read + g write; FedBuff: x, g, step read + step write -- the first arrival of a
+        # buffer skips the step read and the flushing one adds the g write, so 16 on average
+        self.alg_bytes = 16 * self.n_step if self.buff else 12 * self.n_step
         self.client_bytes = 4 * lay.n_f32
         self.result_numel = lay.n_f32
 
