@@ -7,6 +7,11 @@ the aggregator sees it.  `bytes_to_model` parses the zip container and its pickl
 returns tensors that are VIEWS of the received buffer, so the only host copy left is the
 aggregator's pack into its pinned staging row (`ClientSlab.upload`).
 
+`model_to_bytes` is the other direction (comm/mpi/serializer.py:46-50 `model_to_byte`,
+comm/grpc/utils.py:20-24 `serialize_model`): it writes the same archive layout `torch.save`
+does -- so any client's `torch.load` reads it -- but copies each storage once, straight into the
+output buffer, with the copy and the CRC-32 of the big records spread over threads.
+
 The pickle is read by a restricted unpickler that knows exactly the constructs `torch.save`
 emits for a dict of plain tensors (OrderedDict / dict, `_rebuild_tensor_v2`, `_rebuild_parameter`,
 typed storages) and refuses everything else, so unlike a plain `torch.load(weights_only=False)`
@@ -16,11 +21,14 @@ it cannot be made to run code from the file.
 from __future__ import annotations
 
 import collections
+import functools
 import io
 import pickle
 import struct
 import warnings
 import zipfile
+import zlib
+from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, Tuple, Union
 
 import torch
@@ -85,6 +93,37 @@ class _Unpickler(pickle.Unpickler):
         return _StorageRef(str(pid[2]), pid[1].dtype, int(pid[4]))
 
 
+class _BufferFile:
+    """Read-only, seekable file over a memoryview -- just enough for zipfile to find the central
+    directory without copying the archive (io.BytesIO would copy all of it)."""
+
+    def __init__(self, buf: memoryview):
+        self._buf, self._pos = buf, 0
+
+    def seekable(self):
+        return True
+
+    def readable(self):
+        return True
+
+    def tell(self):
+        return self._pos
+
+    def seek(self, off, whence=0):
+        base = 0 if whence == 0 else (self._pos if whence == 1 else len(self._buf))
+        self._pos = max(0, base + off)
+        return self._pos
+
+    def read(self, n=-1):
+        end = len(self._buf) if n is None or n < 0 else min(len(self._buf), self._pos + n)
+        out = bytes(self._buf[self._pos:end])
+        self._pos = max(self._pos, end)
+        return out
+
+    def close(self):
+        pass
+
+
 def _stored_range(buf: memoryview, info: zipfile.ZipInfo) -> Tuple[int, int]:
     """Byte range of an uncompressed member inside the archive buffer."""
     if info.compress_type != zipfile.ZIP_STORED:
@@ -114,7 +153,7 @@ def bytes_to_model(model_bytes: Union[bytes, bytearray, memoryview]) -> Dict[str
     compression is off."""
     buf = memoryview(model_bytes).cast("B")
     try:
-        zf = zipfile.ZipFile(io.BytesIO(buf))     # BytesIO shares nothing, but only reads headers
+        zf = zipfile.ZipFile(_BufferFile(buf))
     except zipfile.BadZipFile as e:
         raise WireFormatError("not a torch.save zip archive (legacy formats are not supported)") from e
     members = {i.filename: i for i in zf.infolist()}
@@ -159,3 +198,181 @@ def _fill_views(out, obj, buf, members, prefix) -> None:
         else:
             whole = torch.frombuffer(buf, dtype=ref.storage.dtype, count=ref.storage.numel, offset=s0)
             out[name] = torch.as_strided(whole, ref.size, ref.stride, ref.offset).clone()
+
+
+# ---------------------------------------------------------------------------------------------
+# state dict -> torch.save-compatible bytes
+
+_DTYPE_STORAGES = {v: k for k, v in _STORAGE_DTYPES.items()}
+_ALIGN = 64                      # torch.save aligns record payloads to 64 bytes
+_CHUNK = 8 << 20                 # bytes per copy / CRC task
+WRITE_THREADS = 8
+
+
+class _StorageMarker:
+    def __init__(self, key: str, dtype: torch.dtype, numel: int):
+        self.key, self.dtype, self.numel = key, dtype, numel
+
+
+def _gf2_times(mat, vec):
+    out, i = 0, 0
+    while vec:
+        if vec & 1:
+            out ^= mat[i]
+        vec >>= 1
+        i += 1
+    return out
+
+
+def _gf2_square(mat):
+    return [_gf2_times(mat, mat[i]) for i in range(32)]
+
+
+@functools.lru_cache(maxsize=64)
+def _append_zeros_operator(nbytes: int):
+    """GF(2) matrix that turns crc32(A) into crc32(A + nbytes zero bytes) (before the final
+    xor with crc32(B)); cached because a model's records have the same lengths every round."""
+    op = [0xEDB88320] + [1 << i for i in range(31)]    # one zero bit
+    for _ in range(3):
+        op = _gf2_square(op)                           # one zero byte
+    result = None
+    n = nbytes
+    while n:
+        if n & 1:
+            result = op if result is None else [_gf2_times(op, col) for col in result]
+        n >>= 1
+        if n:
+            op = _gf2_square(op)
+    return tuple(result)
+
+
+def crc32_combine(crc1: int, crc2: int, len2: int) -> int:
+    """CRC-32 of A+B from crc32(A), crc32(B) and len(B) (what zlib's crc32_combine computes)."""
+    if len2 <= 0:
+        return crc1
+    return _gf2_times(_append_zeros_operator(len2), crc1) ^ crc2
+
+
+class _Pickler(pickle.Pickler):
+    """Emits what torch.save emits for a dict of CPU tensors: `_rebuild_tensor_v2` calls over
+    persistent storage ids; tensors sharing a storage share its record."""
+
+    def __init__(self, file):
+        super().__init__(file, protocol=2)
+        self.records = []            # (key, uint8 tensor over the storage bytes, keep-alive)
+        self._by_storage = {}
+
+    def persistent_id(self, obj):
+        if isinstance(obj, _StorageMarker):
+            return ("storage", getattr(torch, _DTYPE_STORAGES[obj.dtype]), obj.key, "cpu", obj.numel)
+        return None
+
+    def reducer_override(self, obj):
+        if not isinstance(obj, torch.Tensor):
+            return NotImplemented
+        t = obj.detach()
+        if t.device.type != "cpu" or t.layout != torch.strided or t.dtype not in _DTYPE_STORAGES:
+            raise WireFormatError(f"cannot serialise a {t.dtype} tensor on {t.device}")
+        st = t.untyped_storage()
+        item = t.element_size()
+        ident = (st.data_ptr(), st.nbytes(), t.dtype) if st.nbytes() else (id(t), 0, t.dtype)
+        marker = self._by_storage.get(ident)
+        if marker is None:
+            marker = _StorageMarker(str(len(self.records)), t.dtype, st.nbytes() // item)
+            self._by_storage[ident] = marker
+            raw = torch.empty(0, dtype=torch.uint8).set_(st) if st.nbytes() else torch.empty(0, dtype=torch.uint8)
+            self.records.append((marker.key, raw, t))
+        return (torch._utils._rebuild_tensor_v2,
+                (marker, t.storage_offset(), tuple(t.shape), tuple(t.stride()), False,
+                 collections.OrderedDict()))
+
+
+def _local_header(name: bytes, size: int, crc: int, pad: int) -> bytes:
+    extra = b"" if pad == 0 else b"FB" + struct.pack("<H", pad - 4) + b"Z" * (pad - 4)
+    return struct.pack("<IHHHHHIIIHH", 0x04034B50, 0, 0x0800, 0, 0, 0x21, crc, size, size,
+                       len(name), len(extra)) + name + extra
+
+
+def _central_header(name: bytes, size: int, crc: int, offset: int) -> bytes:
+    return struct.pack("<IHHHHHHIIIHHHHHII", 0x02014B50, 0, 0, 0x0800, 0, 0, 0x21, crc, size, size,
+                       len(name), 0, 0, 0, 0, 0, offset) + name
+
+
+def model_to_bytes(state_dict: Dict[str, torch.Tensor], prefix: str = "archive") -> memoryview:
+    """State dict of CPU tensors -> the bytes `torch.save(state_dict, f)` would put in `f`, as far
+    as `torch.load` can tell (same records, pickle and alignment; views of one storage share
+    one record).  Returns a writable byte memoryview (buffer protocol; wrap in `bytes()` where an
+    immutable object is required, e.g. a protobuf field)."""
+    import numpy as np
+
+    if not isinstance(state_dict, dict):
+        raise WireFormatError("expected a state dict")
+    pkl = io.BytesIO()
+    pickler = _Pickler(pkl)
+    pickler.dump(state_dict)
+    small = [("data.pkl", pkl.getvalue()), (".format_version", b"1"), (".storage_alignment", b"64"),
+             ("byteorder", b"little")]
+    tail = [("version", b"3\n")]
+    # layout pass
+    entries = []                     # (name bytes, size, header offset, pad, payload or record index)
+    pos = 0
+
+    def place(name: str, size: int, payload):
+        nonlocal pos
+        nm = f"{prefix}/{name}".encode()
+        data_at = pos + 30 + len(nm)
+        pad = (-(data_at + 4)) % _ALIGN + 4          # extra field is at least its 4-byte header
+        entries.append([nm, size, pos, pad, payload])
+        pos = data_at + pad + size
+
+    for name, data in small:
+        place(name, len(data), data)
+    for key, raw, _ in pickler.records:
+        place(f"data/{key}", raw.numel(), raw)
+    for name, data in tail:
+        place(name, len(data), data)
+    cd_at = pos
+    cd_size = sum(46 + len(e[0]) for e in entries)
+    total = cd_at + cd_size + 22
+    if total >= 0xFFFFFFFF or len(entries) >= 0xFFFF:
+        raise WireFormatError("archives of 4 GiB or more need zip64; use torch.save")
+    # uninitialised, so the pages are first touched by the copy threads rather than zero-filled
+    view = np.empty(total, dtype=np.uint8)
+    out = memoryview(view)
+    # payload pass: big records are copied and checksummed in chunks on a thread pool
+    tasks = []                       # (entry index, chunk start, chunk end)
+    crcs = [0] * len(entries)
+    for i, (nm, size, at, pad, payload) in enumerate(entries):
+        start = at + 30 + len(nm) + pad
+        if isinstance(payload, bytes):
+            out[start:start + size] = payload
+            crcs[i] = zlib.crc32(payload)
+        else:
+            for a in range(0, size, _CHUNK):
+                tasks.append((i, start, a, min(a + _CHUNK, size)))
+
+    def work(task):
+        i, start, a, b = task
+        src = entries[i][4].numpy()[a:b]
+        view[start + a:start + b] = src
+        return i, b - a, zlib.crc32(view[start + a:start + b])
+
+    if tasks:
+        if len(tasks) == 1:
+            done = [work(tasks[0])]
+        else:
+            with ThreadPoolExecutor(max_workers=WRITE_THREADS) as pool:
+                done = list(pool.map(work, tasks))
+        started = set()
+        for i, n, c in done:
+            crcs[i] = c if i not in started else crc32_combine(crcs[i], c, n)
+            started.add(i)
+    cd = bytearray()
+    for i, (nm, size, at, pad, _) in enumerate(entries):
+        hdr = _local_header(nm, size, crcs[i], pad)
+        out[at:at + len(hdr)] = hdr
+        cd += _central_header(nm, size, crcs[i], at)
+    out[cd_at:cd_at + cd_size] = bytes(cd)
+    out[cd_at + cd_size:] = struct.pack("<IHHHHIIH", 0x06054B50, 0, 0, len(entries), len(entries),
+                                        cd_size, cd_at, 0)
+    return out

@@ -62,3 +62,59 @@ def test_refuses_anything_but_a_plain_state_dict():
         wire.bytes_to_model(pickle.dumps({"a": 1}))
     with pytest.raises(wire.WireFormatError):
         wire.bytes_to_model(_save({"x": "not a tensor"}))
+
+
+def _state_for_writing():
+    flat = torch.arange(40, dtype=torch.float32) * 0.25
+    sd = collections.OrderedDict()
+    sd["view_a"] = flat[:24].view(4, 6)                 # two views of one storage
+    sd["view_b"] = flat[24:]
+    sd["strided"] = torch.arange(12.0).reshape(3, 4).t()
+    sd["scalar"] = torch.tensor(5, dtype=torch.int64)
+    sd["i32"] = torch.arange(7, dtype=torch.int32)
+    sd["empty"] = torch.empty(0, 3)
+    sd["param"] = torch.nn.Parameter(torch.ones(2, 2))
+    return sd
+
+
+def test_written_archive_loads_with_torch_load_and_has_valid_checksums():
+    import zipfile
+    sd = _state_for_writing()
+    raw = wire.model_to_bytes(sd)
+    assert zipfile.ZipFile(io.BytesIO(raw)).testzip() is None        # every CRC-32 checks out
+    for weights_only in (True, False):
+        got = torch.load(io.BytesIO(raw), map_location="cpu", weights_only=weights_only)
+        assert isinstance(got, collections.OrderedDict) and list(got) == list(sd)
+        for k in sd:
+            assert got[k].dtype == sd[k].dtype and got[k].shape == sd[k].shape, k
+            assert torch.equal(got[k], sd[k].detach()), k
+        assert got["view_a"].untyped_storage().data_ptr() == got["view_b"].untyped_storage().data_ptr()
+    back = wire.bytes_to_model(raw)
+    assert all(torch.equal(back[k], sd[k].detach()) for k in sd)
+    # same records as torch.save writes, each payload 64-byte aligned
+    ref = io.BytesIO()
+    torch.save(sd, ref)
+    names = lambda b: sorted(i.filename for i in zipfile.ZipFile(io.BytesIO(b)).infolist()
+                             if "serialization_id" not in i.filename)
+    assert names(raw) == names(ref.getvalue())
+    for i in zipfile.ZipFile(io.BytesIO(raw)).infolist():
+        a, _ = wire._stored_range(memoryview(raw), i)
+        assert a % 64 == 0, i.filename
+
+
+def test_large_record_is_checksummed_in_chunks():
+    import zipfile
+    import zlib
+    big = torch.randn((wire._CHUNK // 4) * 3 + 12345)
+    raw = wire.model_to_bytes({"w": big, "n": torch.tensor(3)})
+    zf = zipfile.ZipFile(io.BytesIO(raw))
+    assert zf.testzip() is None
+    assert zf.getinfo("archive/data/0").CRC == zlib.crc32(big.numpy().tobytes())
+    assert torch.equal(torch.load(io.BytesIO(raw), weights_only=True)["w"], big)
+
+
+def test_crc32_combine_matches_zlib():
+    import zlib
+    a, b = bytes(range(256)) * 37, b"federated" * 1001
+    assert wire.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    assert wire.crc32_combine(zlib.crc32(a), zlib.crc32(b""), 0) == zlib.crc32(a)
