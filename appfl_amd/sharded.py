@@ -103,6 +103,40 @@ class ShardedFlatAggregator:
         self.ops.reduce_opt(list(client_slices), list(weights), self.g, self.m, self.v, self.opt,
                             step_ws=step_ws, n=n_local, **self.hp)
 
+    def round_sliced_gather(self, client_slices: Sequence[torch.Tensor], weights: Sequence[float],
+                            out: Optional[torch.Tensor] = None, pieces: int = 4,
+                            step_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`round_sliced` followed by the all-gather of the new global model, pipelined: the
+        slice is aggregated in `pieces` pieces and the all-gather of piece p runs (on RCCL's own
+        stream) while piece p+1 is being aggregated.  On xGMI the gather of a large model takes
+        several times longer than the local round, so this hides the round, not the gather.
+        Returns the padded full vector (rank r's slice at [r*L, (r+1)*L))."""
+        if out is None:
+            out = torch.empty(self.world * self.L, dtype=torch.float32, device=self.device)
+        if out.numel() < self.world * self.L:
+            raise ValueError("gather buffer shorter than world * shard_length")
+        n_local = self.hi - self.lo
+        pieces = max(1, min(int(pieces), self.L // 4 or 1))
+        per = ((self.L + pieces - 1) // pieces + 3) // 4 * 4
+        works = []
+        for a in range(0, self.L, per):
+            b = min(self.L, a + per)
+            live = min(b, n_local) - a          # elements of this piece that hold parameters
+            if live > 0:
+                self.ops.reduce_opt([c[a:] for c in client_slices], list(weights), self.g[a:],
+                                    None if self.m is None else self.m[a:],
+                                    None if self.v is None else self.v[a:], self.opt,
+                                    step_ws=None if step_ws is None else step_ws[a:], n=live,
+                                    **self.hp)
+            if self.world == 1:
+                out[a:b].copy_(self.g[a:b])
+            else:
+                dst = [out[r * self.L + a:r * self.L + b] for r in range(self.world)]
+                works.append(dist.all_gather(dst, self.g[a:b], group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        return out
+
     # -- whole-update mode ------------------------------------------------------------------
     def _reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor) -> None:
         if self.world == 1:

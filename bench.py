@@ -89,6 +89,18 @@ class SyncBench:
     def step(self, events=None):
         self.agg._launch_round(self.K, self.weights, True, events)
 
+    def step_piece(self, lo, hi):
+        """The fused round restricted to elements [lo, hi) of the step segment (lo % 4 == 0)."""
+        slab, lay, g = self.agg._slab, self.agg._layout, self.agg._flats["f32"]
+        hi = min(hi, self.n_step)
+        if hi <= lo:
+            return
+        rows = [slab.row_ptr(k) + 4 * lo for k in range(self.K)]
+        self.agg._ensure_moments()
+        m, v = self.agg._m, self.agg._v
+        self.ops.reduce_opt(rows, self.weights, g[lo:], None if m is None else m[lo:],
+                            None if v is None else v[lo:], self.opt, n=hi - lo, **self.agg._hyper())
+
     def result(self):
         return self.agg._flats["f32"][:self.result_numel]
 
@@ -344,6 +356,37 @@ def main():
         extra["allgather"] = {"value": round(world * b.client_bytes * a.steps / el2 / 1e9, 2),
                               "unit": "GB/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
                               "gathered_bytes_per_rank": world * shard.numel() * 4}
+        if hasattr(b, "step_piece"):
+            # the same, pipelined: the gather of piece p overlaps the aggregation of piece p+1
+            pieces = 4
+            n = shard.numel()
+            per = ((n + pieces - 1) // pieces + 3) // 4 * 4
+            full = torch.empty(world * n, dtype=shard.dtype, device=shard.device)
+
+            def pipelined():
+                works = []
+                for lo in range(0, n, per):
+                    hi = min(n, lo + per)
+                    b.step_piece(lo, hi)
+                    dst = [full[r * n + lo:r * n + hi] for r in range(world)]
+                    works.append(dist.all_gather(dst, shard[lo:hi], async_op=True))
+                for w in works:
+                    w.wait()
+
+            for _ in range(2):
+                pipelined()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                pipelined()
+            barrier()
+            el3 = time.perf_counter() - t0
+            t = torch.tensor([el3], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el3 = float(t.item())
+            extra["allgather_pipelined"] = {
+                "value": round(world * b.client_bytes * a.steps / el3 / 1e9, 2), "unit": "GB/s",
+                "ms_per_step": round(el3 / a.steps * 1e3, 4), "pieces": pieces}
 
     if rank == 0:
         achieved = b.alg_bytes / (kernel_avg_ms * 1e-3) / 1e9

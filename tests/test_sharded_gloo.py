@@ -54,6 +54,12 @@ def _worker(rank, world, port, mode, out):
             _, xs, w = _inputs(r)
             if mode == "sliced":
                 agg.round_sliced([torch.from_numpy(x[lo:hi].copy()) for x in xs], w)
+            elif mode == "pipelined":
+                # slices padded to the shard length like rows of the staging slab
+                rows = [torch.from_numpy(np.concatenate([x[lo:hi], np.zeros(agg.L - (hi - lo), np.float32)]))
+                        for x in xs]
+                full = agg.round_sliced_gather(rows, w, pieces=3)
+                assert torch.equal(full, agg.all_gather_global())
             else:
                 mine = [k for k in range(K) if k % world == rank]
                 agg.round_whole([torch.from_numpy(xs[k]) for k in mine], [w[k] for k in mine])
@@ -64,12 +70,12 @@ def _worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sliced", "whole"])
+@pytest.mark.parametrize("mode", ["sliced", "pipelined", "whole"])
 def test_two_rank_sharded_adam(mode, tmp_path):
     out = str(tmp_path / "g.npy")
     mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
     got, want = np.load(out), _single_process_reference()
-    if mode == "sliced":
+    if mode in ("sliced", "pipelined"):
         # every element sees the same operations in the same order as on one GPU
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     else:

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 HP = dict(lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
 
 
-@pytest.mark.parametrize("mode", ["sliced", "whole"])
+@pytest.mark.parametrize("mode", ["sliced", "pipelined", "whole"])
 def test_single_rank_modes_match_oracle(mode):
     from appfl_amd.sharded import ShardedFlatAggregator
     n, K = 100003, 6
@@ -29,6 +29,10 @@ def test_single_rank_modes_match_oracle(mode):
         dx = [torch.from_numpy(x).cuda() for x in xs]
         if mode == "sliced":
             agg.round_sliced(dx, w)
+        elif mode == "pipelined":
+            pad = torch.zeros(agg.L - n, device="cuda")
+            full = agg.round_sliced_gather([torch.cat([x, pad]) for x in dx], w, pieces=5)
+            assert torch.equal(full, agg.all_gather_global())
         else:
             agg.round_whole(dx, w)
     got = agg.all_gather_global().cpu().numpy()[:n]
