@@ -137,9 +137,12 @@ class ClientSlab:
 
 
 class HostDownloader:
-    """Device -> host copies of flat state vectors into FRESH pageable tensors: one pinned D2H
-    transfer (PCIe rate) into a reusable pinned buffer, then a multi-threaded memcpy that also
-    spreads the first-touch page faults of the new tensor over the copy threads."""
+    """Device -> host copies of flat state vectors into FRESH pageable tensors: pinned D2H
+    transfers (PCIe rate) of DOWNLOAD_CHUNK bytes into a reusable pinned buffer, each followed --
+    while the next one is still in flight -- by a multi-threaded copy into the new tensor, which
+    is first touched through huge pages where the kernel grants them."""
+
+    DOWNLOAD_CHUNK = 32 << 20
 
     def __init__(self):
         self._pinned: Dict[torch.dtype, torch.Tensor] = {}
@@ -151,12 +154,22 @@ class HostDownloader:
         if buf is None or buf.numel() < n:
             buf = torch.empty(n, dtype=flat.dtype, pin_memory=True)
             self._pinned[flat.dtype] = buf
-        buf[:n].copy_(flat[:n], non_blocking=True)
-        torch.cuda.current_stream(flat.device).synchronize()
+        item = flat.element_size()
+        per = max(1, self.DOWNLOAD_CHUNK // item)
+        stream = torch.cuda.current_stream(flat.device)
+        landed = []
+        for a in range(0, n, per):
+            b = min(n, a + per)
+            buf[a:b].copy_(flat[a:b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            landed.append((a, b, ev))
         out = torch.empty(n, dtype=flat.dtype)
-        nbytes = n * flat.element_size()
-        rc = N.load().fa_pack_host(
-            C.c_void_p(out.data_ptr()), (C.c_void_p * 1)(buf.data_ptr()), (C.c_size_t * 1)(0),
-            (C.c_size_t * 1)(nbytes), 1, PACK_THREADS)
-        N.check(rc, "fa_pack_host")
+        lib = N.load()
+        for a, b, ev in landed:
+            ev.synchronize()
+            rc = lib.fa_host_copy_fresh(C.c_void_p(out.data_ptr() + a * item),
+                                        C.c_void_p(buf.data_ptr() + a * item),
+                                        (b - a) * item, PACK_THREADS)
+            N.check(rc, "fa_host_copy_fresh")
         return out

@@ -218,6 +218,13 @@ int fa_synth_fill(float* p, const float* base, size_t n, uint64_t seed, uint64_t
  */
 int fa_pack_host(void* dst, const void* const* src, const size_t* dst_off, const size_t* nbytes,
                  int T, int threads);
+/*
+ * Threaded copy of `nbytes` from `src` (e.g. a pinned download buffer) into a FRESHLY allocated
+ * pageable buffer `dst` whose pages have not been touched yet; asks the kernel for huge pages
+ * first.  Last leg of handing the new global model back as fresh CPU tensors
+ * (misc/memory_utils.py:15-36 clone_state_dict_optimized).
+ */
+int fa_host_copy_fresh(void* dst, const void* src, size_t nbytes, int threads);
 
 #ifdef __cplusplus
 }
