@@ -340,9 +340,14 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         const unsigned slots = gridDim.x * rounds;
         tlen = (((a.n + slots - 1) / slots) + 63u) & ~63u;
         const unsigned total = (a.n + tlen - 1) / tlen;
-        if (blockIdx.x >= total) return;
-        ntiles = (total - blockIdx.x + gridDim.x - 1) / gridDim.x;
-        r0 = blockIdx.x * tlen;
+        // Blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous run of
+        // a round's tiles (slot = xcd * blocks_per_xcd + index within the XCD) rather than every
+        // eighth one: a consistent +0.5 % (fewer rows open per XCD's slice of the fabric).
+        unsigned slot = blockIdx.x;
+        if (gridDim.x % 8 == 0) slot = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+        if (slot >= total) return;
+        ntiles = (total - slot + gridDim.x - 1) / gridDim.x;
+        r0 = slot * tlen;
         r1 = a.n;
         tstride = gridDim.x * tlen;
     } else {
