@@ -265,7 +265,15 @@ __global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
     constexpr unsigned kTile = kThreads * VPT;
     const unsigned full = a.n / kTile;  // tiles that need no bounds check
     const unsigned tiles = (a.n + kTile - 1) / kTile;
-    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+    // Blocks are dispatched round-robin over the 8 XCDs.  Inside every window of 8*R tiles
+    // each XCD takes R consecutive tiles instead of every eighth one (measured +4-5 % for the
+    // two-moment optimizers at K = 32..64, +-1 % elsewhere); a ragged last window keeps the
+    // plain order.
+    constexpr unsigned R = (OPT >= FA_OPT_ADAM) ? 32u : 128u;
+    for (unsigned t0 = blockIdx.x; t0 < tiles; t0 += gridDim.x) {
+        unsigned t = t0;
+        const unsigned win = t0 & ~(8u * R - 1u);
+        if (VEC == 4 && win + 8u * R <= tiles) t = win + (t0 & 7u) * R + ((t0 >> 3) & (R - 1u));
         if (t < full)
             reduce_tile<OPT, VEC, VPT, U, NT, false>(a, t * kTile);
         else
