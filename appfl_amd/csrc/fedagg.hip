@@ -854,10 +854,9 @@ constexpr unsigned kLeanTileVectors = 1u << 20;   // 16 MiB of g
 int g_write_through = 1;   // fa_tune's nt field: bit 1 set = plain result stores
 int g_interleave = 1;      // fa_tune's nt field: bit 2 set = contiguous per-block ranges in the persistent kernel
 
-// Below this many clients per launch the persistent kernel loses to the tile-per-block one: its
-// two-deep pipeline of 8-client sets pads a short client list with repeated loads, and its write
-// bursts stall the one-wave-per-SIMD loaders for longer than they save.
-constexpr int kStashMinClients = 16;
+// From this many clients on, the tile-per-block kernel on a long vector takes two vectors per
+// thread instead of one.
+constexpr int kTwoVectorClients = 16;
 
 int device_cu_count() {
     static int cus[64] = {0};
@@ -910,16 +909,20 @@ int launch_reduce_u(const ReduceArgs& a, int unroll, hipStream_t st) {
     }
 }
 
-// Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.  The
-// optimizers with two moment vectors stay on the tile-per-block kernel up to ~100 clients: with
-// four result vectors per tile the LDS budget holds only three tiles per burst, and many
-// resident waves hide their six state streams better than one wave per SIMD (measured 2-5 %
-// faster at K = 16..64, 2 % slower at K = 100).
-constexpr int kStashMinClientsTwoMoments = 96;
+// Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.  It
+// wins where one result vector per tile leaves room for long write bursts and the client list
+// is long (FedAvg from ~32 clients: +2-4 %, FedAvgM from ~48: +2 %).  The optimizers with two
+// moment vectors stay on the tile-per-block kernel: with four result vectors per tile the LDS
+// budget holds only three tiles per burst, and many resident waves hide their six state streams
+// better than one wave per SIMD (2-4 % faster at every K measured, 16..128).
+int stash_min_clients(int opt) {
+    if (opt == FA_OPT_NONE) return 32;
+    if (opt == FA_OPT_AVGM) return 48;
+    return FA_KCHUNK + 1;
+}
 bool takes_stash_path(int opt, int K, uint64_t nvec) {
     if (g_shape.stash < 0) return K > kStashUnroll;
-    const int kmin = opt >= FA_OPT_ADAM ? kStashMinClientsTwoMoments : kStashMinClients;
-    return g_shape.stash > 0 && K >= kmin &&
+    return g_shape.stash > 0 && K >= stash_min_clients(opt) &&
            nvec >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile;
 }
 
@@ -934,7 +937,7 @@ int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
         // two-moment optimizers, +2-4 % for plain FedAvg at K = 2..15); short vectors are launch
         // bound and do better with fewer, fatter blocks.
         const bool lean = a.n >= kLeanTileVectors;
-        vpt = !lean ? 4 : (a.K >= kStashMinClients ? 2 : 1);
+        vpt = !lean ? 4 : (a.K >= kTwoVectorClients ? 2 : 1);
         unroll = lean ? 16 : 8;
     }
     switch (vpt) {

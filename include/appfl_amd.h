@@ -67,8 +67,9 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * non-temporal client loads, bit 1: plain instead of write-through result stores, bit 2: the
  * persistent kernel gives each block one contiguous range instead of every gridDim-th tile),
  * grid cap (<= 0: default) of the tile-per-block kernel, and from how many 16-KiB tiles per CU
- * on a launch of >= 16 clients takes the persistent kernel that parks results in LDS and writes
- * them in bursts (stash: 0 never, < 0 always, default 2).  Results do not depend on it.
+ * on a launch with a long client list (FedAvg >= 32, FedAvgM >= 48 clients) takes the persistent
+ * kernel that parks results in LDS and writes them in bursts (stash: 0 never, < 0 always for
+ * more than 8 clients, default 2).  Results do not depend on it.
  * Process-wide; not synchronised with concurrent calls.
  */
 int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);

@@ -281,7 +281,7 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
     tiles to blocks: same bits as the oracle for the final state, the optional step output and
     the step-only mode."""
     from appfl_amd import ops
-    K = 17 if n > 1000000 else 11
+    K = 33 if n > 1000000 else 11
     if n > 1000000:
         assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
         assert ops.reduce_kernel_name(K, n, "adam") == "reduce_kernel"
