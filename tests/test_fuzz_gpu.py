@@ -116,3 +116,39 @@ def test_random_mixes_means_and_arrivals(seed):
             ops.buff_accum(dx[j], alpha, g, s, first=(j == 0), gradient_based=grad, flush=(j == B - 1))
         assert golden_util.same_bits(g.cpu().numpy(), gw), what + " (buff g)"
         assert golden_util.same_bits(s.cpu().numpy(), sw), what + " (buff step)"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_state_dict_rounds(seed):
+    """Drop-in classes on random state-dict layouts (tensor counts, shapes, integer entries,
+    client counts and sample sizes changing per round) against the numpy oracle."""
+    import appfl_amd.aggregator as A
+    import scenarios as S
+    from oracle import aggregators as OA
+    rng = np.random.default_rng(777 + seed)
+    cls = ["FedAvgAggregator", "FedAvgMAggregator", "FedAdamAggregator", "FedYogiAggregator",
+           "FedAdagradAggregator"][seed % 5]
+    spec = {}
+    for t in range(int(rng.integers(1, 9))):
+        kind = "f32" if rng.random() < 0.75 else ("i64" if rng.random() < 0.6 else "i32")
+        dims = int(rng.integers(0, 4))
+        shape = tuple(int(rng.integers(1, 40)) for _ in range(dims))
+        spec[f"layer{t}.{'weight' if kind == 'f32' else 'count'}"] = (shape, kind)
+    spec["tail.weight"] = ((int(rng.choice([1, 5, 1027, 70001])),), "f32")
+    mode = "sample_size" if seed % 2 else "equal"
+    cfg = dict(S.HP[cls], client_weights_mode=mode)
+    dev, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    for agg in (dev, ora):
+        for c in range(12):
+            agg.set_client_sample_size(c, int(3 + 7 * c))
+    for r in range(4):
+        K = int(rng.integers(1, 12))
+        ids = [int(c) for c in rng.permutation(12)[:K]]
+        models = {c: S.make_state(spec, seed=1000 * seed + 20 * r + c) for c in ids}
+        got = dev.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        assert list(got) == list(want)
+        for k in want:
+            g = got[k].numpy()
+            assert g.dtype == want[k].dtype and g.shape == want[k].shape, (seed, r, k)
+            assert golden_util.same_bits(g, want[k]), f"seed {seed} round {r} {cls} entry {k}"
