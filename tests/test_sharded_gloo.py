@@ -70,10 +70,11 @@ def _worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sliced", "pipelined", "whole"])
-def test_two_rank_sharded_adam(mode, tmp_path):
+@pytest.mark.parametrize("mode,world", [("sliced", 2), ("pipelined", 2), ("whole", 2),
+                                        ("pipelined", 3), ("whole", 3)])
+def test_multi_rank_sharded_adam(mode, world, tmp_path):
     out = str(tmp_path / "g.npy")
-    mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
     got, want = np.load(out), _single_process_reference()
     if mode in ("sliced", "pipelined"):
         # every element sees the same operations in the same order as on one GPU
