@@ -167,7 +167,10 @@ __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&
     const float* gsrc = a.apply ? a.g : a.g_ro;
 #pragma unroll
     for (int p = 0; p < VPT; ++p) {
-        r.g[p] = load_state<VEC>(gsrc, idx[p]);
+        // g, m and v are read once per round like the client rows, but whether the streaming
+        // (nt) policy pays differs: measured +2 % for g under plain FedAvg, -1.5 % for g beside
+        // two moment streams, +1.5-7 % for m / v of the two-moment optimizers, -1 % for FedAvgM's v.
+        r.g[p] = (OPT == FA_OPT_NONE) ? load_stream<VEC, true>(gsrc, idx[p]) : load_state<VEC>(gsrc, idx[p]);
         if (a.step_in) {
             r.s[p] = load_state<VEC>(a.step_in, idx[p]);
         } else {
@@ -213,8 +216,8 @@ __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&
 #pragma unroll
     for (int p = 0; p < VPT; ++p) {
         if (OPT != FA_OPT_NONE) {
-            r.v[p] = load_state<VEC>(a.v, idx[p]);
-            if (OPT != FA_OPT_AVGM) r.m[p] = load_state<VEC>(a.m, idx[p]);
+            r.v[p] = (OPT >= FA_OPT_ADAM) ? load_stream<VEC, true>(a.v, idx[p]) : load_state<VEC>(a.v, idx[p]);
+            if (OPT != FA_OPT_AVGM) r.m[p] = load_stream<VEC, true>(a.m, idx[p]);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float mj = (OPT != FA_OPT_AVGM) ? r.m[p].e[j] : 0.0f;
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(kThreads) void async_mix_kernel(const float* x, flo
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
             xv[p] = load_stream<VEC>(x, idx[p]);
-            gv[p] = load_state<VEC>(g, idx[p]);
+            gv[p] = load_stream<VEC>(g, idx[p]);   // every stream here is read once
         }
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
@@ -729,12 +732,12 @@ __global__ __launch_bounds__(kThreads) void buff_accum_kernel(const float* x, fl
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
             xv[p] = load_stream<VEC>(x, idx[p]);
-            gv[p] = load_state<VEC>(g, idx[p]);
+            gv[p] = load_stream<VEC>(g, idx[p]);     // streamed like x: +3 % over cached loads
             if (first) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) sv[p].e[j] = 0.0f;
             } else {
-                sv[p] = load_state<VEC>(step, idx[p]);
+                sv[p] = load_stream<VEC>(step, idx[p]);
             }
         }
 #pragma unroll
