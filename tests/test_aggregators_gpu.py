@@ -130,7 +130,7 @@ def test_chunked_get_parameters():
 
 
 def test_config1_mnist_cnn_serial_harness_matches_oracle():
-    """BASELINE config #1 (MNIST CNN, FedAvg, 2 clients, serial) through the harness: the HIP
+    """Benchmark configuration 1 (MNIST CNN, FedAvg, 2 clients, serial) through the harness: the HIP
     aggregator and the oracle agree bit for bit over three rounds."""
     import appfl_amd.aggregator as A
     from appfl_amd import workloads as W

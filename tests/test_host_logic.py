@@ -1,5 +1,5 @@
 """Host-side logic that needs no GPU: the C ABI surface, layout / row packing, chunking rule,
-workload tables, the serial harness (BASELINE config #1 plumbing) driven by the oracle."""
+workload tables, the serial harness (plumbing of benchmark configuration 1) driven by the oracle."""
 
 import ctypes as C
 import os
