@@ -229,9 +229,16 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         straight into the pinned staging row, skipping the per-tensor CPU copies `torch.load`
         makes (agent/server.py:505-513).  Returns the state dict of views to hand to the
         scheduler / `aggregate` in place of the deserialised model."""
+        import io
+
         from .. import wire
 
-        local_model = wire.bytes_to_model(model_bytes)
+        try:
+            local_model = wire.bytes_to_model(model_bytes)
+        except wire.WireFormatError:
+            # not a plain torch.save archive of tensors (legacy format, other containers): let
+            # torch read it, still without executing anything from the payload
+            local_model = torch.load(io.BytesIO(model_bytes), map_location="cpu", weights_only=True)
         self.stage(client_id, local_model)
         return local_model
 
