@@ -115,6 +115,9 @@ class ClientSlab:
                 (C.c_void_p * T)(*host_src), (C.c_size_t * T)(*host_off),
                 (C.c_size_t * T)(*host_len), T, PACK_THREADS)
             N.check(rc, "fa_pack_host")
+        if dev_items or missing:
+            # device-side sources may still be being written on the caller's stream
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.copy_stream):
             if T:
                 self.slab[k].copy_(self.pinned[slot], non_blocking=True)
