@@ -54,6 +54,7 @@ SIGNATURES = {
     "fa_fill_f32": (_i, [_p, _f, _sz, _p]),
     "fa_synth_fill": (_i, [_p, _p, _sz, _u64, _u64, _f, _p]),
     "fa_pack_host": (_i, [_p, _p, _p, _p, _i, _i]),
+    "fa_pack_host_window": (_i, [_p, _p, _p, _p, _i, _sz, _sz, _i]),
     "fa_host_copy_fresh": (_i, [_p, _p, _sz, _i]),
 }
 

@@ -1475,6 +1475,25 @@ int fa_pack_host(void* dst, const void* const* src, const size_t* dst_off, const
     return FA_OK;
 }
 
+int fa_pack_host_window(void* dst, const void* const* src, const size_t* dst_off,
+                        const size_t* nbytes, int T, size_t win_lo, size_t win_hi, int threads) {
+    if (!dst || !src || !dst_off || !nbytes || T < 0 || win_hi < win_lo) return FA_ERR_INVALID;
+    // the parts of the pieces that fall inside [win_lo, win_hi) of the destination
+    std::vector<const void*> s2;
+    std::vector<size_t> o2, n2;
+    for (int t = 0; t < T; ++t) {
+        const size_t b = dst_off[t], e = dst_off[t] + nbytes[t];
+        const size_t lo = b > win_lo ? b : win_lo, hi = e < win_hi ? e : win_hi;
+        if (lo >= hi) continue;
+        if (!src[t]) return FA_ERR_INVALID;
+        s2.push_back(static_cast<const char*>(src[t]) + (lo - b));
+        o2.push_back(lo);
+        n2.push_back(hi - lo);
+    }
+    if (s2.empty()) return FA_OK;
+    return fa_pack_host(dst, s2.data(), o2.data(), n2.data(), static_cast<int>(s2.size()), threads);
+}
+
 int fa_host_copy_fresh(void* dst, const void* src, size_t nbytes, int threads) {
     if ((!dst || !src) && nbytes) return FA_ERR_INVALID;
     if (!nbytes) return FA_OK;

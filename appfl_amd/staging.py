@@ -18,6 +18,7 @@ from . import _native as N
 from .layout import Layout
 
 PACK_THREADS = 8
+UPLOAD_WINDOW = 32 << 20
 
 
 class ClientSlab:
@@ -109,18 +110,23 @@ class ClientSlab:
         if self.slot_free[slot] is not None:
             self.slot_free[slot].synchronize()
         T = len(host_src)
-        if T:
-            rc = N.load().fa_pack_host(
-                C.c_void_p(self.pinned[slot].data_ptr()),
-                (C.c_void_p * T)(*host_src), (C.c_size_t * T)(*host_off),
-                (C.c_size_t * T)(*host_len), T, PACK_THREADS)
-            N.check(rc, "fa_pack_host")
         if dev_items or missing:
             # device-side sources may still be being written on the caller's stream
             self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        if T:
+            # pack and transfer in windows of the row, so the PCIe copy of one window runs while
+            # the next is being packed (a single large client would otherwise pay both in turn)
+            srcs, offs, lens = ((C.c_void_p * T)(*host_src), (C.c_size_t * T)(*host_off),
+                                (C.c_size_t * T)(*host_len))
+            pinned, lib = self.pinned[slot], N.load()
+            for a in range(0, self.row_bytes, UPLOAD_WINDOW):
+                b = min(self.row_bytes, a + UPLOAD_WINDOW)
+                rc = lib.fa_pack_host_window(C.c_void_p(pinned.data_ptr()), srcs, offs, lens, T,
+                                             a, b, PACK_THREADS)
+                N.check(rc, "fa_pack_host_window")
+                with torch.cuda.stream(self.copy_stream):
+                    self.slab[k, a:b].copy_(pinned[a:b], non_blocking=True)
         with torch.cuda.stream(self.copy_stream):
-            if T:
-                self.slab[k].copy_(self.pinned[slot], non_blocking=True)
             for e, t in dev_items:
                 self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(t.view(-1), non_blocking=True)
             for e in missing:

@@ -220,6 +220,12 @@ int fa_synth_fill(float* p, const float* base, size_t n, uint64_t seed, uint64_t
 int fa_pack_host(void* dst, const void* const* src, const size_t* dst_off, const size_t* nbytes,
                  int T, int threads);
 /*
+ * fa_pack_host restricted to the destination byte window [win_lo, win_hi): lets a host pack a
+ * large row chunk by chunk and start the transfer of each chunk while the next is being packed.
+ */
+int fa_pack_host_window(void* dst, const void* const* src, const size_t* dst_off,
+                        const size_t* nbytes, int T, size_t win_lo, size_t win_hi, int threads);
+/*
  * Threaded copy of `nbytes` from `src` (e.g. a pinned download buffer) into a FRESHLY allocated
  * pageable buffer `dst` whose pages have not been touched yet; asks the kernel for huge pages
  * first.  Last leg of handing the new global model back as fresh CPU tensors
