@@ -9,7 +9,9 @@ tensors and hands them to the aggregator (agent/server.py:505-525, sync_schedule
 
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -145,20 +147,70 @@ class ClientSlab:
             torch.cuda.current_stream(self.device).wait_event(self.last_copy)
 
 
+class _PinnedPool:
+    """Pinned host buffers handed out as the memory of result tensors.  A tensor made with
+    `torch.frombuffer(lease)` keeps `lease` (a numpy view of the pinned buffer) referenced from
+    its storage, so the finalizer of `lease` fires exactly when the last tensor sharing that
+    storage -- views included -- has died; only then does the buffer go back on the free list."""
+
+    MAX_BYTES = 8 << 30            # pinned memory held by live + free leases; beyond it: no lease
+
+    def __init__(self):
+        self._free = collections.deque()
+        self._held = 0
+
+    def lease(self, nbytes: int):
+        """(lease ndarray of nbytes, True) or (None, False) when the pool is exhausted."""
+        best = None
+        for _ in range(len(self._free)):
+            buf = self._free.popleft()
+            if buf.numel() >= nbytes and (best is None or buf.numel() < best.numel()):
+                if best is not None:
+                    self._free.append(best)
+                best = buf
+            else:
+                self._free.append(buf)
+        if best is None:
+            size = max(nbytes, 1 << 20)
+            if self._held + size > self.MAX_BYTES:
+                return None
+            best = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+            self._held += size
+        lease = best.numpy()[:nbytes]
+        weakref.finalize(lease, self._free.append, best)
+        return lease
+
+
 class HostDownloader:
-    """Device -> host copies of flat state vectors into FRESH pageable tensors: pinned D2H
-    transfers (PCIe rate) of DOWNLOAD_CHUNK bytes into a reusable pinned buffer, each followed --
-    while the next one is still in flight -- by a multi-threaded copy into the new tensor, which
-    is first touched through huge pages where the kernel grants them."""
+    """Device -> host copies of flat state vectors into tensors nobody else holds.
+
+    Preferred: the result tensor's memory IS a pinned buffer leased from a pool, so the D2H
+    transfer (PCIe rate) lands in place and nothing is copied on the host; the buffer returns to
+    the pool when the caller drops the last tensor that views it.  When the pool is exhausted
+    (a caller keeping many results alive): pinned D2H transfers of DOWNLOAD_CHUNK bytes into a
+    reusable staging buffer, each followed -- while the next one is still in flight -- by a
+    multi-threaded copy into a fresh pageable tensor first touched through huge pages."""
 
     DOWNLOAD_CHUNK = 32 << 20
 
-    def __init__(self):
+    def __init__(self, pool: Optional[_PinnedPool] = None):
         self._pinned: Dict[torch.dtype, torch.Tensor] = {}
+        self._pool = pool if pool is not None else _PinnedPool()
 
     def fetch(self, flat: torch.Tensor, n: int) -> torch.Tensor:
         if n == 0:
             return torch.empty(0, dtype=flat.dtype)
+        item = flat.element_size()
+        lease = self._pool.lease(n * item) if self._pool is not None else None
+        if lease is not None:
+            out = torch.frombuffer(lease, dtype=flat.dtype, count=n)
+            del lease
+            out.copy_(flat[:n], non_blocking=True)
+            torch.cuda.current_stream(flat.device).synchronize()
+            return out
+        return self._fetch_pageable(flat, n)
+
+    def _fetch_pageable(self, flat: torch.Tensor, n: int) -> torch.Tensor:
         buf = self._pinned.get(flat.dtype)
         if buf is None or buf.numel() < n:
             buf = torch.empty(n, dtype=flat.dtype, pin_memory=True)

@@ -254,3 +254,31 @@ def test_client_tensors_already_on_the_device():
         for k in want:
             assert not got[k].is_cuda
             assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (r, k)
+
+
+def test_results_live_in_leased_pinned_buffers_that_are_never_reused_while_held():
+    """Returned tensors view a pinned buffer leased from a pool; a result (or any view of it)
+    kept by the caller must stay intact over later rounds, and its buffer is reused only after
+    the caller dropped it."""
+    import gc
+
+    import appfl_amd.aggregator as A
+    cfg = dict(S.HP["FedAvgAggregator"], client_weights_mode="equal")
+    agg = A.FedAvgAggregator(None, cfg, None)
+    kept, copies = [], []
+    for r in range(5):
+        out = agg.aggregate({c: S.make_state(S.RAGGED, seed=31 * r + c) for c in range(2)})
+        assert not out["w"].is_cuda
+        kept.append(out["w"][100:200])                  # only a view survives the round
+        copies.append(out["w"][100:200].clone())
+        del out
+    for view, copy in zip(kept, copies):
+        assert torch.equal(view, copy)
+    pool = agg._dl._pool
+    held_before = pool._held
+    del kept
+    gc.collect()
+    assert len(pool._free) >= 4
+    for r in range(3):                                   # steady state: no new pinned memory
+        agg.aggregate({c: S.make_state(S.RAGGED, seed=77 * r + c) for c in range(2)})
+    assert pool._held == held_before
