@@ -73,8 +73,11 @@ class ClientSlab:
         """Order this round's uploads after the kernels that read the slab last round."""
         self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
 
-    def upload(self, k: int, state: Dict[str, torch.Tensor], fill_missing_from=None) -> None:
-        """Pack `state` into row k.  Entries of the layout that `state` lacks and that take the
+    def upload(self, k: int, state: Dict[str, torch.Tensor], fill_missing_from=None,
+               on_window=None) -> None:
+        """Pack `state` into row k (`on_window(a, b, event)`, if given, is called after the
+        transfer of each window [a, b) of the row has been enqueued; only valid when every entry
+        of `state` is a host tensor).  Entries of the layout that `state` lacks and that take the
         weighted step are filled from `fill_missing_from` (the global fp32 vector), which makes
         their difference zero -- the reference skips such a client for that entry
         (fedavg_aggregator.py:360-361); a missing plain-mean entry raises KeyError (:289)."""
@@ -128,6 +131,12 @@ class ClientSlab:
                 N.check(rc, "fa_pack_host_window")
                 with torch.cuda.stream(self.copy_stream):
                     self.slab[k, a:b].copy_(pinned[a:b], non_blocking=True)
+                    if on_window is not None:
+                        landed = torch.cuda.Event()
+                        landed.record(self.copy_stream)
+                if on_window is not None:
+                    # lets the caller start work on bytes [a, b) of the row once `landed` fires
+                    on_window(a, b, landed)
         with torch.cuda.stream(self.copy_stream):
             for e, t in dev_items:
                 self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(t.view(-1), non_blocking=True)
@@ -209,6 +218,16 @@ class HostDownloader:
             torch.cuda.current_stream(flat.device).synchronize()
             return out
         return self._fetch_pageable(flat, n)
+
+    def lease(self, dtype: torch.dtype, n: int) -> Optional[torch.Tensor]:
+        """An n-element result tensor on a leased pinned buffer for a caller that fills it
+        itself (piecewise, on its own stream); None when the pool is exhausted."""
+        if n == 0 or self._pool is None:
+            return None
+        lease = self._pool.lease(n * torch.empty((), dtype=dtype).element_size())
+        if lease is None:
+            return None
+        return torch.frombuffer(lease, dtype=dtype, count=n)
 
     def _fetch_pageable(self, flat: torch.Tensor, n: int) -> torch.Tensor:
         buf = self._pinned.get(flat.dtype)

@@ -282,3 +282,32 @@ def test_results_live_in_leased_pinned_buffers_that_are_never_reused_while_held(
     for r in range(3):                                   # steady state: no new pinned memory
         agg.aggregate({c: S.make_state(S.RAGGED, seed=77 * r + c) for c in range(2)})
     assert pool._held == held_before
+
+
+@pytest.mark.parametrize("gradient_based", [False, True])
+def test_fedasync_pipelined_arrival_matches_plain_arrival(gradient_based, monkeypatch):
+    """The windowed upload / mix / download pipeline of large FedAsync arrivals, forced onto a
+    small model with tiny windows (several windows, a ragged last one, entries outside the
+    weighted segment): same bits as the plain path and as the oracle."""
+    import appfl_amd.aggregator as A
+    from appfl_amd import staging
+    cfg = dict(S.STALENESS["polynomial"], alpha=0.9, num_clients=3, gradient_based=gradient_based)
+    plain = A.FedAsyncAggregator(None, cfg, None)
+    piped = A.FedAsyncAggregator(None, cfg, None)
+    ora = OA.OracleFedAsync(None, cfg, None)
+    piped.PIPELINE_MIN_ELEMENTS = 0
+    plain.PIPELINE_MIN_ELEMENTS = 1 << 60
+    for i in range(6):
+        cid = i % 3
+        st = S.make_state(S.RAGGED, seed=800 + 13 * i, gradient=gradient_based,
+                          scale=0.01 if gradient_based else 0.02)
+        want = plain.aggregate(cid, {k: v.clone() for k, v in st.items()})
+        ref = ora.aggregate(cid, {k: v.clone() for k, v in st.items()})
+        monkeypatch.setattr(staging, "UPLOAD_WINDOW", 64 << 10)
+        got = piped.aggregate(cid, {k: v.clone() for k, v in st.items()})
+        monkeypatch.setattr(staging, "UPLOAD_WINDOW", 32 << 20)
+        assert list(got) == list(want)
+        for k in want:
+            assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape
+            assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (i, k)
+            assert golden_util.same_bits(got[k].numpy(), ref[k]), (i, k)
