@@ -228,3 +228,28 @@ def test_other_entry_points_across_the_segment_seam():
         want = np.empty_like(base_w)
         O.mean(xs, want)
         _same(g_mean, a, b, want, "mean")
+
+
+def test_config5_whole_1p3b_vector_on_one_gpu():
+    """The 1.3 B-parameter, K = 32 case un-sharded (166 GB of client rows in one GPU's HBM):
+    three launch segments; sampled windows including both seams and the tail."""
+    n, K = 1_300_000_000, 32
+    free, _ = torch.cuda.mem_get_info()
+    if free < (K + 2) * n * 4 + (4 << 30):
+        pytest.skip("not enough free device memory for 166 GB of client rows")
+    w = [1.0 / K] * K
+    seeds = [7000 + k for k in range(K)]
+    base = torch.empty(n, dtype=torch.float32, device="cuda")
+    ops.synth_fill(base, BASE_SEED, scale=0.05)
+    slab = _device_rows(K, n, seeds, base)
+    g = base.clone()
+    ops.reduce_opt([slab[k] for k in range(K)], w, g, n=n)
+    torch.cuda.synchronize()
+    L = 1 << 15
+    wins = _windows(n, 40, L) + [(s - L, s + L) for s in (1 << 29, 1 << 30)]
+    for a, b in wins:
+        base_w = O.synth_fill(b - a, BASE_SEED, first=a, scale=0.05)
+        O.reduce_opt(_host_rows(a, b, seeds, base_w), w, base_w)
+        _same(g, a, b, base_w, "g")
+    del slab, g, base
+    torch.cuda.empty_cache()
