@@ -183,7 +183,10 @@ class _PinnedPool:
             size = max(nbytes, 1 << 20)
             if self._held + size > self.MAX_BYTES:
                 return None
-            best = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+            try:
+                best = torch.empty(size, dtype=torch.uint8, pin_memory=True)
+            except RuntimeError:       # the host refuses to lock more pages: no lease
+                return None
             self._held += size
         lease = best.numpy()[:nbytes]
         weakref.finalize(lease, self._free.append, best)
