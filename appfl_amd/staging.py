@@ -169,7 +169,8 @@ class _PinnedPool:
         self._held = 0
 
     def lease(self, nbytes: int):
-        """(lease ndarray of nbytes, True) or (None, False) when the pool is exhausted."""
+        """A numpy view of `nbytes` bytes of a pinned buffer (smallest free one that fits, else a
+        new one), or None when the pool is exhausted."""
         best = None
         for _ in range(len(self._free)):
             buf = self._free.popleft()
@@ -182,7 +183,11 @@ class _PinnedPool:
         if best is None:
             size = max(nbytes, 1 << 20)
             if self._held + size > self.MAX_BYTES:
-                return None
+                # give back the free buffers that were too small before giving up
+                while self._free:
+                    self._held -= self._free.popleft().numel()
+                if self._held + size > self.MAX_BYTES:
+                    return None
             try:
                 best = torch.empty(size, dtype=torch.uint8, pin_memory=True)
             except RuntimeError:       # the host refuses to lock more pages: no lease
