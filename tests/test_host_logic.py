@@ -34,7 +34,10 @@ def test_argument_checks_without_touching_the_gpu():
     lib = N.load()
     assert lib.fa_reduce_opt(None, None, 0, None, None, None, 0, 0, 0, 0, 0, 0, None, None, None) == -1
     assert lib.fa_tune(3, 8, 1, 0, 4) == -1 and lib.fa_tune(4, 8, 1, 0, 4) == 0
+    assert lib.fa_tune(0, 8, 1, 0, 2) == 0          # back to the defaults
     assert lib.fa_pack_host(None, None, None, None, 0, 1) == -1
+    assert lib.fa_pack_host_window(None, None, None, None, 0, 0, 1, 1) == -1
+    assert lib.fa_host_copy_fresh(None, None, 8, 1) == -1
 
 
 def test_pack_host_matches_numpy():
@@ -117,3 +120,30 @@ def test_serial_harness_runs_config1_plumbing_with_the_oracle():
     want = a["fc2.bias"].numpy() + (np.float32(0.75) * (b["fc2.bias"].numpy() - a["fc2.bias"].numpy())
                                     + np.float32(0.25) * np.float32(0.0))
     assert np.allclose(out["fc2.bias"], want, rtol=0, atol=1e-7)
+
+
+def test_pack_host_window_and_fresh_copy():
+    rng = np.random.default_rng(1)
+    sizes = [300, 70000, 0, 5 * 1024 * 1024 + 3]
+    srcs = [rng.integers(0, 255, s, dtype=np.uint8) for s in sizes]
+    offs, pos = [], 16
+    for s in sizes:
+        offs.append(pos)
+        pos += s + 9
+    want = np.zeros(pos, np.uint8)
+    for a, o in zip(srcs, offs):
+        want[o:o + a.size] = a
+    dst = np.zeros(pos, np.uint8)
+    T = len(sizes)
+    args = ((C.c_void_p * T)(*[a.ctypes.data if a.size else None for a in srcs]),
+            (C.c_size_t * T)(*offs), (C.c_size_t * T)(*sizes), T)
+    step = 1 << 20
+    for lo in range(0, pos, step):       # windows cut through the pieces
+        assert N.load().fa_pack_host_window(C.c_void_p(dst.ctypes.data), *args, lo, min(pos, lo + step), 5) == 0
+        done = min(pos, lo + step)
+        assert np.array_equal(dst[:done], want[:done]) and not dst[done:].any()
+    fresh = np.empty(9 * 1024 * 1024 + 11, np.uint8)
+    src = rng.integers(0, 255, fresh.size, dtype=np.uint8)
+    assert N.load().fa_host_copy_fresh(C.c_void_p(fresh.ctypes.data), C.c_void_p(src.ctypes.data),
+                                       fresh.size, 6) == 0
+    assert np.array_equal(fresh, src)
