@@ -311,3 +311,21 @@ def test_fedasync_pipelined_arrival_matches_plain_arrival(gradient_based, monkey
             assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape
             assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (i, k)
             assert golden_util.same_bits(got[k].numpy(), ref[k]), (i, k)
+
+
+@pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedYogiAggregator"])
+def test_more_clients_than_one_launch_holds(cls):
+    """131 clients: the round runs as two launches carrying the partial step."""
+    import appfl_amd.aggregator as A
+    cfg = dict(S.HP[cls], client_weights_mode="sample_size")
+    dev, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    K = 131
+    for agg in (dev, ora):
+        for c in range(K):
+            agg.set_client_sample_size(c, 5 + (c * 7) % 23)
+    spec = {"w": ((4099,), "f32"), "b": ((3, 5), "f32"), "n": ((), "i64")}
+    for r in range(2):
+        models = {c: S.make_state(spec, seed=500 * r + c) for c in range(K)}
+        got, want = dev.aggregate(models), ora.aggregate(models)
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k]), (r, k)
