@@ -292,16 +292,48 @@ class FedBuffAggregator(FedAsyncAggregator):
             lay = self._layout
             if self._step_flats is None:
                 self._step_flats = lay.alloc_state(self.device)
-            self._upload(local_model)
             first = self.buff_size == 0            # :116-124 zero the buffer
             flush = self.buff_size + 1 == self.K   # :74-75
+            early = None if flush else self._download_early()
+            self._upload(local_model)
             self._launch_arrival(self._alpha_t(client_id), first, flush)
             self.buff_size += 1
             if flush:
                 self.global_step += 1
                 self.buff_size = 0
             self.client_step[client_id] = self.global_step   # :100
+            if early is not None:
+                torch.cuda.current_stream(self.device).synchronize()   # the arrival's kernels
+                self._down_stream.synchronize()
+                return early
             out = self._download()
             if flush:
                 self._sync_model(self.model, out)
             return out
+
+    def _download_early(self) -> Optional[Dict[str, torch.Tensor]]:
+        """An arrival that does not flush the buffer leaves the global model as it is, so its
+        copy for the caller (fedbuff_aggregator.py:101-105 clones it on every call) can travel
+        back while the arrival is still being uploaded: the transfers share the full-duplex
+        link instead of queueing.  None when no pinned lease is to be had."""
+        lay = self._layout
+        if lay.n_f32 < self.PIPELINE_MIN_ELEMENTS:
+            return None
+        host = {}
+        for key, dtype, n in (("f32", torch.float32, lay.n_f32), ("i64", torch.int64, lay.count[MEAN_I64]),
+                              ("i32", torch.int32, lay.count[MEAN_I32])):
+            if n == 0:
+                host[key] = torch.empty(0, dtype=dtype)
+                continue
+            host[key] = self._dl.lease(dtype, n)
+            if host[key] is None:
+                return None
+        if getattr(self, "_down_stream", None) is None:
+            self._down_stream = torch.cuda.Stream(device=self.device)
+        # after whatever changed the global model last (a flush on the compute stream)
+        self._down_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._down_stream):
+            for key, t in host.items():
+                if t.numel():
+                    t.copy_(self._flats[key][:t.numel()], non_blocking=True)
+        return lay.views(host)

@@ -329,3 +329,24 @@ def test_more_clients_than_one_launch_holds(cls):
         got, want = dev.aggregate(models), ora.aggregate(models)
         for k in want:
             assert golden_util.same_bits(got[k].numpy(), want[k]), (r, k)
+
+
+def test_fedbuff_early_download_matches_plain_path():
+    """Non-flushing FedBuff arrivals send the (unchanged) global model back while the arrival
+    uploads; forced onto a small model: same records as the plain path and the oracle."""
+    import appfl_amd.aggregator as A
+    cfg = dict(S.STALENESS["polynomial"], alpha=0.9, num_clients=3, K=3)
+    plain, early = A.FedBuffAggregator(None, cfg, None), A.FedBuffAggregator(None, cfg, None)
+    ora = OA.OracleFedBuff(None, cfg, None)
+    plain.PIPELINE_MIN_ELEMENTS = 1 << 60
+    early.PIPELINE_MIN_ELEMENTS = 0
+    for i in range(8):
+        cid = i % 3
+        st = S.make_state(S.RAGGED, seed=900 + 11 * i)
+        want = plain.aggregate(cid, {k: v.clone() for k, v in st.items()})
+        got = early.aggregate(cid, {k: v.clone() for k, v in st.items()})
+        ref = ora.aggregate(cid, {k: v.clone() for k, v in st.items()})
+        for k in want:
+            assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape
+            assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (i, k)
+            assert golden_util.same_bits(got[k].numpy(), ref[k]), (i, k)
