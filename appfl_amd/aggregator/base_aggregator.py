@@ -63,13 +63,41 @@ def resolve_device(cfg: Any) -> torch.device:
     return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
 
 
+class _DeviceLock:
+    """Re-entrant lock that also makes the aggregator's GPU the current device while held:
+    kernel launches and stream queries go to the current device, and a server process may
+    have set another one (or run several aggregators on different GPUs)."""
+
+    def __init__(self, device: Optional[torch.device]):
+        self._lock = threading.RLock()
+        self._index = device.index if device is not None and device.type == "cuda" else None
+        self._prev = []
+
+    def __enter__(self):
+        self._lock.acquire()
+        prev = None
+        if self._index is not None:
+            prev = torch.cuda.current_device()
+            if prev != self._index:
+                torch.cuda.set_device(self._index)
+        self._prev.append(prev)
+        return self
+
+    def __exit__(self, *exc):
+        prev = self._prev.pop()
+        if prev is not None and prev != self._index:
+            torch.cuda.set_device(prev)
+        self._lock.release()
+        return False
+
+
 class DeviceStateMixin:
     """Lock shared by aggregate / get_parameters: the schedulers serialise `aggregate`, but
     `get_parameters` is called without their lock (base_scheduler.py:67,76 of the reference),
     and here both enqueue work on one stream and read one set of device buffers."""
 
     def _init_lock(self):
-        self._lock = threading.RLock()
+        self._lock = _DeviceLock(getattr(self, "device", None))
 
     @staticmethod
     def _sync_model(model: Optional[torch.nn.Module], state: Dict[str, torch.Tensor]):
