@@ -133,9 +133,10 @@ class ShardedFedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     return {k: v.clone().detach() for k, v in self.model.state_dict().items()}
             return self._assemble()
 
-    def _assemble(self) -> Dict[str, torch.Tensor]:
+    def _assemble(self, full: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         lay = self._layout
-        full = self._flat.all_gather_global()              # RCCL all-gather of the slices
+        if full is None:
+            full = self._flat.all_gather_global()          # RCCL all-gather of the slices
         host = {"f32": torch.cat([full[:lay.count[STEP]].cpu(),
                                   self._small["f32"][:lay.count[MEAN_F32]].cpu()]),
                 "i64": self._small["i64"][:lay.count[MEAN_I64]].cpu(),
@@ -150,17 +151,19 @@ class ShardedFedAvgAggregator(BaseAggregator, DeviceStateMixin):
             lay, fl = self._layout, self._flat
             K, n_local = len(local_models), fl.hi - fl.lo
             pin = self.device.type == "cuda"
-            rows = []
-            if lay.count[STEP] and n_local:
-                g_host = fl.g[:n_local].cpu()
-                for model in local_models.values():
-                    buf = torch.empty(n_local, dtype=torch.float32, pin_memory=pin)
-                    self._pack_slice(model, buf, g_host)
-                    rows.append(buf.to(self.device, non_blocking=pin))
+            rows, full = [], None
+            if lay.count[STEP]:
+                if n_local:
+                    g_host = fl.g[:n_local].cpu()
+                    for model in local_models.values():
+                        buf = torch.empty(n_local, dtype=torch.float32, pin_memory=pin)
+                        self._pack_slice(model, buf, g_host)
+                        rows.append(buf.to(self.device, non_blocking=pin))
                 ws = None
-                if K > 128:
+                if K > 128 and n_local:
                     ws = torch.empty(n_local, dtype=torch.float32, device=self.device)
-                fl.round_sliced(rows, self._client_weights(local_models), step_ws=ws)
+                # every rank takes part in the gathers, also one whose slice is empty
+                full = fl.round_sliced_gather(rows, self._client_weights(local_models), step_ws=ws)
             # replicated plain means of the small entries (fedavg_aggregator.py:285-296)
             for cls, key in ((MEAN_F32, "f32"), (MEAN_I64, "i64"), (MEAN_I32, "i32")):
                 cnt = lay.count[cls]
@@ -171,6 +174,6 @@ class ShardedFedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     parts = [model[e.name].detach().reshape(-1).to(e.dtype) for e in lay.entries if e.cls == cls]
                     xs.append(torch.cat(parts).to(self.device))
                 self.ops.mean(xs, self._small[key], n=cnt)
-            out = self._assemble()
+            out = self._assemble(full)
             self._sync_model(self.model, out)
             return out
