@@ -139,3 +139,39 @@ def test_two_rank_state_dict_aggregator_matches_single_process_oracle(tmp_path):
         for k in want:
             assert got[r][k].dtype == want[k].dtype and got[r][k].shape == want[k].shape, k
             assert got[r][k].tobytes() == want[k].tobytes(), (r, k)
+
+
+TINY = {"w": ((5,), "f32"), "n": ((), "i64")}
+
+
+def _tiny_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        agg = ShardedFedAvgAggregator(None, {"client_weights_mode": "equal"}, None, algorithm="FedAvg",
+                                      device="cpu", backend=cpu_backend)
+        recs = []
+        for r in range(2):
+            local = {c: S.make_state(TINY, seed=40 * r + c) for c in range(3)}
+            recs.append({k: v.numpy().copy() for k, v in agg.aggregate(local).items()})
+        assert agg._flat.hi - agg._flat.lo == (4, 1, 0)[rank]
+        if rank == 2:                                   # the rank whose slice is empty
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_on_a_five_element_model_one_slice_empty(tmp_path):
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_tiny_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    got = np.load(out, allow_pickle=True)
+    ora = OA.OracleFedAvg(None, {"client_weights_mode": "equal"}, None)
+    for r in range(2):
+        want = ora.aggregate({c: S.make_state(TINY, seed=40 * r + c) for c in range(3)})
+        for k in want:
+            assert got[r][k].tobytes() == want[k].tobytes(), (r, k)
