@@ -14,6 +14,7 @@
 #include <string.h>
 #include <sys/mman.h>
 
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1182,6 +1183,39 @@ int buff_accum_dispatch(const float* x, double alpha_t, int gradient_based, floa
     return buff_accum_mode<0, FLUSH>(x, alpha, g, step, first, n, a16, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Library-owned carry workspace of fa_reduce_opt_static: device memory every GPU the library runs
+// on holds until the process ends.  In host code `scratch` is only a handle of the symbol; the
+// device address comes from hipGetSymbolAddress, once per device, and is what the kernels get.
+
+}  // namespace
+
+static __device__ __align__(256) float scratch[FA_STATIC_WS_FLOATS];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Address of the current device's copy of `scratch` (looked up on the first call per device).
+int scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_code(e);
+    if (dev < 0 || dev >= kMaxDevices) return FA_ERR_INVALID;
+    std::lock_guard<std::mutex> hold(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return hip_code(e);
+        if (!p) return FA_ERR_INVALID;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return FA_OK;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1218,6 +1252,7 @@ const char* fa_error_string(int code) {
         case FA_ERR_INVALID: return "invalid argument";
         case FA_ERR_ALIGN: return "buffer not aligned to its element size";
         case FA_ERR_WORKSPACE: return "K > FA_KCHUNK needs a step workspace";
+        case FA_ERR_TOO_LARGE: return "n exceeds FA_STATIC_WS_FLOATS, the library-owned workspace";
     }
     if (code <= FA_ERR_HIP) return hipGetErrorString(static_cast<hipError_t>(FA_ERR_HIP - code));
     return "unknown error";
@@ -1235,6 +1270,21 @@ int fa_reduce_apply(const float* const* x, const double* w, int K, float* g, siz
                     float* step_ws, fa_stream_t stream) {
     return fa_reduce_opt(x, w, K, g, nullptr, nullptr, n, FA_OPT_NONE, 0, 0, 0, 0, nullptr,
                          step_ws, stream);
+}
+
+int fa_reduce_opt_static(const float* const* x, const double* w, int K, float* g, float* m,
+                         float* v, size_t n, int opt, double lr, double beta1, double beta2,
+                         double tau, float* step_out, fa_stream_t stream) {
+    float* ws = nullptr;
+    if (K > FA_KCHUNK && !step_out) {
+        // the partial step of the first client chunks is carried through the library's array
+        if (n > static_cast<size_t>(FA_STATIC_WS_FLOATS)) return FA_ERR_TOO_LARGE;
+        int rc = scratch_for_current_device(&ws);
+        if (rc != FA_OK) return rc;
+    }
+    ReduceCall c{x, w, K, g, nullptr, m, v, n, opt, make_hyper(lr, beta1, beta2, tau),
+                 step_out, ws, 1};
+    return reduce_dispatch(c, as_stream(stream));
 }
 
 int fa_reduce_opt_slab(const float* slab, size_t stride, const double* w, int K, float* g,

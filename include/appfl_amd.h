@@ -36,6 +36,7 @@ enum {
     FA_ERR_INVALID = -1,   /* NULL pointer, K <= 0, unknown opt code, ...                */
     FA_ERR_ALIGN = -2,     /* a buffer is not aligned to its element size                */
     FA_ERR_WORKSPACE = -3, /* K > FA_KCHUNK needs a step workspace and none was given     */
+    FA_ERR_TOO_LARGE = -4, /* n beyond the library-owned workspace of fa_reduce_opt_static */
     FA_ERR_HIP = -1000     /* FA_ERR_HIP - hipError_t: a HIP runtime call failed          */
 };
 
@@ -97,6 +98,24 @@ int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);
 int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float* m, float* v,
                   size_t n, int opt, double lr, double beta1, double beta2, double tau,
                   float* step_out, float* step_ws, fa_stream_t stream);
+
+/*
+ * fa_reduce_opt for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arithmetic, arguments and results as fa_reduce_opt, except that the carry workspace a
+ * round of K > FA_KCHUNK clients needs (when step_out is NULL) is not passed in: it is a
+ * library-owned array of FA_STATIC_WS_FLOATS floats (128 MiB) that every GPU the library runs
+ * on holds from its first use until the process ends.  The call allocates and frees nothing.
+ * K > FA_KCHUNK with step_out == NULL and n > FA_STATIC_WS_FLOATS returns FA_ERR_TOO_LARGE
+ * before anything is enqueued.  All calls on one GPU share that GPU's array (its contents are
+ * whatever the last call left; every launch writes its part before reading it, so nothing has
+ * to be cleared): calls that overlap in time on one GPU -- different streams or threads --
+ * race on it and must be serialised by the caller.
+ */
+#define FA_STATIC_WS_FLOATS (32u << 20)
+int fa_reduce_opt_static(const float* const* x, const double* w, int K, float* g, float* m,
+                         float* v, size_t n, int opt, double lr, double beta1, double beta2,
+                         double tau, float* step_out, fa_stream_t stream);
 
 /* FedAvg only: fa_reduce_opt with opt = FA_OPT_NONE and no moments. */
 int fa_reduce_apply(const float* const* x, const double* w, int K, float* g, size_t n,
