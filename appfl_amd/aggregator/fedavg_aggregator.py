@@ -68,7 +68,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
     _OPT = "none"
 
     def __init__(self, model: Optional[torch.nn.Module] = None, aggregator_configs: Any = None,
-                 logger: Optional[Any] = None):
+                 logger: Optional[Any] = None, *, device=None):
         self.model = model
         self.logger = logger
         self.aggregator_configs = aggregator_configs if aggregator_configs is not None else {}
@@ -80,7 +80,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self.named_parameters = None
         self.step: Dict[str, torch.Tensor] = {}
         self.model_chunk_size = None
-        self.device = resolve_device(self.aggregator_configs)
+        self.device = (torch.device(device) if device is not None
+                       else resolve_device(self.aggregator_configs))
+        self._ops = ops          # the flat kernels (libappfl_amd.so through ctypes)
         self._layout: Optional[Layout] = None
         self._flats: Optional[Dict[str, torch.Tensor]] = None      # global state
         self._slab: Optional[ClientSlab] = None
@@ -140,7 +142,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 sizes = ({k: v.numel() * v.element_size() for k, v in source.items()}
                          if source is not None else
                          {e.name: e.numel * torch.empty((), dtype=e.dtype).element_size()
-                          for e in self._layout.entries})
+                          for e in self._names_layout().entries})
                 if sum(sizes.values()) > self.model_chunk_size:
                     chunks = split_names_by_size(sizes, self.model_chunk_size)
                     chunk_idx = requested_chunk_id if requested_chunk_id is not None else 0
@@ -168,6 +170,10 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 with torch.no_grad():
                     return {k: v.clone().detach() for k, v in self.model.state_dict().items()}
             return self._download()
+
+    def _names_layout(self) -> Layout:
+        """The layout that lists the global state's entries by name."""
+        return self._layout
 
     # -- state ------------------------------------------------------------------------------------
     def _init_global_state(self, first_model: Dict[str, torch.Tensor]):
@@ -221,6 +227,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             if row == 0:
                 self._slab.begin_round()
             self._slab.upload(row, local_model, fill_missing_from=self._flats["f32"])
+            if self._slab.has_device_sources:
+                # the caller may overwrite its device tensors as soon as this returns
+                self._slab.wait_uploads()
             self._prestaged[client_id] = (row, local_model)
 
     def stage_bytes(self, client_id, model_bytes) -> Dict:
@@ -245,8 +254,11 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
     def _stage(self, local_models) -> None:
         """Pack and upload every client's state dict into the device slab (client order =
         dict order = arrival order, which is the reduction order); clients already uploaded by
-        `stage` keep their rows."""
-        if self._staged_for is local_models:
+        `stage` keep their rows.  Inside `aggregate` the round's dict is staged once: a
+        `compute_steps` override that calls back into this class finds it done.  A stand-alone
+        `compute_steps` call always stages afresh (the schedulers refill and reuse one dict
+        object across rounds, sync_scheduler.py:46,80, so identity alone proves nothing)."""
+        if self._staged_for is not None and self._staged_for is local_models:
             return
         K = len(local_models)
         taken = len(self._prestaged)
@@ -267,7 +279,6 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             nxt += 1
         self._slab.end_round()
         self._prestaged = {}
-        self._staged_for = local_models
 
     def _hyper(self) -> Dict[str, float]:
         return {}
@@ -300,6 +311,10 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         optimizer / apply kernel (or, un-fused, the apply of a step computed by compute_steps),
         then the plain means of the entries that bypass the step.  `events` = (start, end)
         torch.cuda.Event pair recorded around the fused kernel (benchmark timing)."""
+        self._launch_step(K, weights, fused, events)
+        self._launch_means(K)
+
+    def _launch_step(self, K: int, weights, fused: bool = True, events=None) -> None:
         lay = self._layout
         n_step = lay.count[STEP]
         g = self._flats["f32"]
@@ -307,28 +322,33 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             if n_step:
                 self._ensure_moments()
                 ws = None
-                if K > ops.kchunk():
+                if K > self._ops.kchunk():
                     if self._step_flat is None:
                         self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
                     ws = self._step_flat
                 if events:
                     events[0].record()
-                ops.reduce_opt(self._rows(K, 0), weights, g, self._m, self._v, self._OPT,
-                               step_ws=ws, n=n_step, **self._hyper())
+                self._ops.reduce_opt(self._rows(K, 0), weights, g, self._m, self._v, self._OPT,
+                                     step_ws=ws, n=n_step, **self._hyper())
                 if events:
                     events[1].record()
         else:
             for e in lay.entries:
                 if e.name in self.step:
-                    ops.apply_step(lay.view(self._flats, e.name).view(-1),
-                                   self.step[e.name].contiguous().view(-1))
-        # entries that bypass the step: plain mean over clients (fedavg_aggregator.py:285-296)
+                    self._ops.apply_step(lay.view(self._flats, e.name).view(-1),
+                                         self.step[e.name].contiguous().view(-1))
+
+    def _launch_means(self, K: int) -> None:
+        """Entries that bypass the step: plain mean over clients (fedavg_aggregator.py:285-296)."""
+        lay = self._layout
+        n_step = lay.count[STEP]
         if lay.count[MEAN_F32]:
-            ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), g[n_step:], n=lay.count[MEAN_F32])
+            self._ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), self._flats["f32"][n_step:],
+                           n=lay.count[MEAN_F32])
         if lay.count[MEAN_I64]:
-            ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
+            self._ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
         if lay.count[MEAN_I32]:
-            ops.mean(self._rows(K, lay.seg_byte[MEAN_I32]), self._flats["i32"], n=lay.count[MEAN_I32])
+            self._ops.mean(self._rows(K, lay.seg_byte[MEAN_I32]), self._flats["i32"], n=lay.count[MEAN_I32])
 
     # -- aggregate: fedavg_aggregator.py:150-320 -----------------------------------------------------
     def aggregate(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict]], **kwargs) -> Dict:
@@ -350,10 +370,13 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._stage(local_models)
             fused = getattr(type(self).compute_steps, "_appfl_amd_native", False)
             if not fused:
-                self.compute_steps(local_models)          # user override (may call super())
+                self._staged_for = local_models           # staged for the duration of this call
+                try:
+                    self.compute_steps(local_models)      # user override (may call super())
+                finally:
+                    self._staged_for = None
             self._launch_round(K, self._client_weights(local_models), fused)
             self.step = {}
-            self._staged_for = None
             out = self._download()
             self._sync_model(self.model, out)
             return out
@@ -497,7 +520,7 @@ class _AdaptiveAggregator(FedAvgMAggregator):
             tau = cfg_require(self.aggregator_configs, "server_adapt_param")
             self._m = torch.zeros(n, dtype=torch.float32, device=self.device)
             self._v = torch.empty(n, dtype=torch.float32, device=self.device)
-            ops.fill(self._v, tau ** 2)
+            self._ops.fill(self._v, tau ** 2)
 
 
 class FedAdamAggregator(_AdaptiveAggregator):

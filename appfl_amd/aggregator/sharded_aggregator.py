@@ -1,13 +1,20 @@
 """State-dict level FedAvg-family aggregation with the parameter axis sharded over the GPUs of
 one node (one process per GPU, SPMD).
 
-Every rank calls `aggregate(local_models)` with the SAME client state dicts (e.g. an MPI server
-that broadcasts the received bytes, or ranks reading one shared-memory copy).  Rank r packs and
-uploads only slice r of every client's weighted entries, runs the fused kernel on its slice
-(`ShardedFlatAggregator.round_sliced`, no collective in the arithmetic), and one RCCL
-all-gather of the updated slices gives every rank the whole new model, which it returns like
-`FedAvgAggregator.aggregate` would.  Integer / non-parameter entries (a few KB) are averaged
-redundantly on every rank.  Results are bit-identical to the single-GPU aggregators.
+Every rank calls `aggregate(local_models)` (and `stage(client_id, model)`, if the scheduler
+stages on arrival) with the SAME client state dicts, e.g. an MPI server that broadcasts the
+received bytes, or ranks reading one shared-memory copy.  Rank r is a `FedAvgAggregator` whose
+rows hold only ITS blocks of the weighted entries (`ShardMap`, `WindowedLayout`): the native
+packer copies just those windows of every client tensor into the pinned slot, the slab row is
+1/R as long, the fused kernel runs on the local blocks with no collective in the arithmetic, and
+the RCCL all-gathers of the block rows -- pipelined behind the kernels -- leave the whole new
+model on every rank, which downloads it like the single-GPU class.  Integer / non-parameter
+entries (a few KB) are averaged redundantly on every rank.  Results are bit-identical to the
+single-GPU aggregators.
+
+Collectives happen in `aggregate` only.  `get_parameters` is local: it serves the model every
+rank holds after the last gather (or the initial state), so one rank may answer client requests
+at any time (base_scheduler.py:67,76 call it outside the scheduler's lock) without the others.
 
 No counterpart in the reference, whose server is a single CPU process
 (comm/mpi/mpi_server_communicator.py:56-90); the semantics of a round are those of
@@ -16,164 +23,146 @@ algorithm/aggregator/fedavg_aggregator.py:150-404 and the optimizer subclasses.
 
 from __future__ import annotations
 
-import ctypes as C
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, Optional
 
 import torch
 import torch.distributed as dist
 
-from .. import _native as N
-from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout
-from ..sharded import ShardedFlatAggregator
-from .base_aggregator import BaseAggregator, DeviceStateMixin, cfg_get, cfg_require
+from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout, WindowedLayout
+from ..sharded import ShardMap, round_gather_pipelined
+from ..staging import ClientSlab
+from .base_aggregator import cfg_require
+from .fedavg_aggregator import FedAvgAggregator, _native
 
 _OPTS = {"FedAvg": "none", "FedAvgM": "avgm", "FedAdam": "adam", "FedYogi": "yogi",
          "FedAdagrad": "adagrad"}
 
 
-class ShardedFedAvgAggregator(BaseAggregator, DeviceStateMixin):
+class ShardedFedAvgAggregator(FedAvgAggregator):
     """`algorithm` selects the server optimizer: FedAvg | FedAvgM | FedAdam | FedYogi |
-    FedAdagrad (same configuration fields as the single-GPU classes)."""
+    FedAdagrad (same configuration fields as the single-GPU classes).  `backend` / `device` exist
+    for the tests only: they rehearse the multi-rank logic on CPU tensors with gloo and a
+    stand-in kernel module; the product leaves both unset (HIP kernels, current GPU)."""
 
     def __init__(self, model: Optional[torch.nn.Module] = None, aggregator_configs: Any = None,
                  logger: Optional[Any] = None, algorithm: str = "FedAvg", group=None,
-                 backend=None, device=None):
-        self.model = model
-        self.logger = logger
-        self.aggregator_configs = aggregator_configs if aggregator_configs is not None else {}
-        self.client_weights_mode = cfg_get(self.aggregator_configs, "client_weights_mode", "equal")
-        self.named_parameters = ({n for n, _ in model.named_parameters()} if model is not None else None)
-        self.opt = _OPTS[algorithm]
+                 backend=None, device=None, pieces: Optional[int] = None):
+        super().__init__(model, aggregator_configs, logger, device=device)
+        self._OPT = _OPTS[algorithm]
+        if backend is not None:
+            self._ops = backend
         self.group = group
-        if backend is None:
-            from .. import ops as backend
-        self.ops = backend
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        self.device = torch.device(device)
-        self._layout: Optional[Layout] = None
-        self._flat: Optional[ShardedFlatAggregator] = None
-        self._small: Optional[Dict[str, torch.Tensor]] = None    # replicated mean_f32 / i64 / i32 state
-        self._init_lock()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._pieces = pieces
+        self._full_layout: Optional[Layout] = None
+        self._map: Optional[ShardMap] = None
+        self._gathered: Optional[torch.Tensor] = None   # padded full step segment, on every rank
 
+    # -- hyper-parameters and moments of the selected optimizer ---------------------------------
     def _hyper(self) -> Dict[str, float]:
         c = self.aggregator_configs
-        if self.opt == "none":
+        if self._OPT == "none":
             return {}
-        if self.opt == "avgm":
+        if self._OPT == "avgm":
             return {"beta1": cfg_require(c, "server_momentum_param_1")}
         return {"lr": cfg_require(c, "server_learning_rate"), "tau": cfg_require(c, "server_adapt_param"),
                 "beta1": cfg_require(c, "server_momentum_param_1"),
-                "beta2": cfg_require(c, "server_momentum_param_2") if self.opt != "adagrad" else 0.0}
+                "beta2": cfg_require(c, "server_momentum_param_2") if self._OPT != "adagrad" else 0.0}
 
-    def _client_weights(self, local_models) -> List[float]:
-        sizes = getattr(self, "client_sample_size", None) or {}
-        total = sum(sizes[c] for c in local_models if c in sizes)
-        return [sizes[c] / total if (self.client_weights_mode == "sample_size" and c in sizes and total > 0)
-                else 1.0 / len(local_models) for c in local_models]
+    def _ensure_moments(self) -> None:
+        L = self._map.L
+        z = dict(dtype=torch.float32, device=self.device)
+        if self._OPT != "none" and self._v is None:
+            self._v = torch.zeros(L, **z)
+            if self._OPT != "avgm":       # fedadam_aggregator.py:41-50: m = 0, v = tau**2
+                self._m = torch.zeros(L, **z)
+                self._ops.fill(self._v, cfg_require(self.aggregator_configs, "server_adapt_param") ** 2)
 
-    # -- host-side packing of this rank's slice ------------------------------------------------
-    def _pack_slice(self, state: Dict[str, torch.Tensor], dst: torch.Tensor, fill: torch.Tensor) -> None:
-        """dst[0 : hi-lo] <- elements [lo, hi) of the client's weighted entries (fp32, flat
-        order); an entry the client lacks is filled from `fill` (this rank's slice of g), which
-        makes its difference zero (fedavg_aggregator.py:360-361)."""
-        lo, hi = self._flat.lo, self._flat.hi
-        src, off, nb, keep = [], [], [], []
-        for e in self._layout.entries:
-            if e.cls != STEP:
-                continue
-            a, b = max(e.offset, lo), min(e.offset + e.numel, hi)
-            if a >= b:
-                continue
-            t = state.get(e.name)
-            if t is None:
-                dst[a - lo:b - lo].copy_(fill[a - lo:b - lo])
-                continue
-            t = t.detach().to(torch.float32).contiguous().cpu()
-            keep.append(t)
-            src.append(t.data_ptr() + 4 * (a - e.offset))
-            off.append(4 * (a - lo))
-            nb.append(4 * (b - a))
-        T = len(src)
-        if T:
-            rc = N.load().fa_pack_host(C.c_void_p(dst.data_ptr()), (C.c_void_p * T)(*src),
-                                       (C.c_size_t * T)(*off), (C.c_size_t * T)(*nb), T, 8)
-            N.check(rc, "fa_pack_host")
+    # -- state ------------------------------------------------------------------------------------
+    def _names_layout(self) -> Layout:
+        return self._full_layout
 
-    def _init_state(self, first_model) -> None:
+    def _init_global_state(self, first_model: Dict[str, torch.Tensor]):
+        """fedavg_aggregator.py:228-271 on this rank's blocks; the gathered copy of the whole
+        weighted segment is built locally (every rank sees the same initial values)."""
         if self.model is not None:
-            ms = self.model.state_dict()
-            init = {n: ms[n] for n in first_model if n in ms}
+            model_state = self.model.state_dict()
+            init = {n: model_state[n] for n in first_model if n in model_state}
         else:
             init = dict(first_model)
-        self._layout = lay = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
-                                    self.named_parameters)
-        hp = self._hyper()
-        self._flat = ShardedFlatAggregator(max(lay.count[STEP], 1), self.opt, device=self.device,
-                                           group=self.group, backend=self.ops, **hp)
-        step_full = torch.zeros(max(lay.count[STEP], 1), dtype=torch.float32)
-        small = {"f32": torch.zeros(max(lay.count[MEAN_F32], 1), dtype=torch.float32),
-                 "i64": torch.zeros(max(lay.count[MEAN_I64], 1), dtype=torch.int64),
-                 "i32": torch.zeros(max(lay.count[MEAN_I32], 1), dtype=torch.int32)}
-        for e in lay.entries:
-            t = init[e.name].detach().reshape(-1).cpu()
-            if e.cls == STEP:
-                step_full[e.offset:e.offset + e.numel] = t
-            else:
-                small[Layout.flat_key(e.cls)][e.offset:e.offset + e.numel] = t
-        self._flat.load_global(step_full.to(self.device))
-        self._small = {k: v.to(self.device) for k, v in small.items()}
+        full = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()], self.named_parameters)
+        smap = ShardMap(full.count[STEP], self.world, self.rank, self._pieces)
+        lay = WindowedLayout(full, smap.windows(), smap.L)
+        flats = lay.alloc_state(self.device)
+        gathered = torch.zeros(smap.P, dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            for e in lay.entries:
+                src = init[e.name].detach().reshape(-1)[e.src_offset:e.src_offset + e.numel]
+                off = lay.flat_offset(e)
+                flats[Layout.flat_key(e.cls)][off:off + e.numel].copy_(src)
+            for e in full.entries:
+                if e.cls == STEP:
+                    gathered[e.offset:e.offset + e.numel].copy_(init[e.name].detach().reshape(-1))
+        self._full_layout, self._map, self._layout = full, smap, lay
+        self._flats, self._gathered = flats, gathered
+        self._slab = ClientSlab(lay, self.device)
 
-    def get_parameters(self, **kwargs) -> Dict:
-        with self._lock:
-            if self._layout is None:
-                if self.model is None:
-                    raise ValueError("Model is not provided to the aggregator.")
-                with torch.no_grad():
-                    return {k: v.clone().detach() for k, v in self.model.state_dict().items()}
-            return self._assemble()
+    @property
+    def global_state(self) -> Optional[Dict[str, torch.Tensor]]:
+        """{name: device tensor} snapshot of the whole global state as this rank holds it after
+        the last gather (the gathered weighted segment and the replicated small entries)."""
+        if self._full_layout is None:
+            return None
+        return self._full_layout.views(self._device_state())
 
-    def _assemble(self, full: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        lay = self._layout
-        if full is None:
-            full = self._flat.all_gather_global()          # RCCL all-gather of the slices
-        host = {"f32": torch.cat([full[:lay.count[STEP]].cpu(),
-                                  self._small["f32"][:lay.count[MEAN_F32]].cpu()]),
-                "i64": self._small["i64"][:lay.count[MEAN_I64]].cpu(),
-                "i32": self._small["i32"][:lay.count[MEAN_I32]].cpu()}
-        return lay.views(host)
+    def _device_state(self) -> Dict[str, torch.Tensor]:
+        full, L = self._full_layout, self._map.L
+        n_step = full.count[STEP]
+        f32 = self._gathered[:n_step]
+        if full.count[MEAN_F32]:
+            f32 = torch.cat([f32, self._flats["f32"][L:L + full.count[MEAN_F32]]])
+        return {"f32": f32, "i64": self._flats["i64"], "i32": self._flats["i32"]}
+
+    def _moment_views(self, flat):
+        """The moments live sharded (`_m` / `_v` hold this rank's blocks); no per-name views."""
+        return {}
+
+    def _download(self, names=None) -> Dict[str, torch.Tensor]:
+        """Fresh CPU copy of the whole global state -- local, no collective."""
+        full, L = self._full_layout, self._map.L
+        n_step, n_mean = full.count[STEP], full.count[MEAN_F32]
+        host = {"f32": self._dl.fetch_parts([self._gathered[:n_step],
+                                             self._flats["f32"][L:L + n_mean]]),
+                "i64": self._dl.fetch(self._flats["i64"], full.count[MEAN_I64]),
+                "i32": self._dl.fetch(self._flats["i32"], full.count[MEAN_I32])}
+        out = full.views(host)
+        if names is not None:
+            return {n: out[n] for n in names if n in out}
+        return out
+
+    # -- the round ----------------------------------------------------------------------------------
+    def _launch_step(self, K: int, weights, fused: bool = True, events=None) -> None:
+        """Fused kernel on every local block, each followed by the all-gather of its block row.
+        Every rank takes part in every gather, also one whose blocks are all empty."""
+        smap = self._map
+        self._ensure_moments()
+        ws = None
+        if K > self._ops.kchunk() and smap.n_local:
+            if self._step_flat is None:
+                self._step_flat = torch.empty(smap.L, dtype=torch.float32, device=self.device)
+            ws = self._step_flat
+        round_gather_pipelined(self._ops, smap, self._rows(K, 0) if smap.n_local else [], weights,
+                               self._flats["f32"], self._m, self._v, self._OPT, self._hyper(),
+                               self._gathered, self.group, ws)
+
+    @_native
+    def compute_steps(self, local_models):
+        raise NotImplementedError("the sharded aggregator runs the fused round only; subclass the "
+                                  "single-GPU classes to override compute_steps")
 
     def aggregate(self, local_models: Dict, **kwargs) -> Dict:
-        with self._lock:
-            first = next(iter(local_models.values()))
-            if self._layout is None:
-                self._init_state(first)
-            lay, fl = self._layout, self._flat
-            K, n_local = len(local_models), fl.hi - fl.lo
-            pin = self.device.type == "cuda"
-            rows, full = [], None
-            if lay.count[STEP]:
-                if n_local:
-                    g_host = fl.g[:n_local].cpu()
-                    for model in local_models.values():
-                        buf = torch.empty(n_local, dtype=torch.float32, pin_memory=pin)
-                        self._pack_slice(model, buf, g_host)
-                        rows.append(buf.to(self.device, non_blocking=pin))
-                ws = None
-                if K > 128 and n_local:
-                    ws = torch.empty(n_local, dtype=torch.float32, device=self.device)
-                # every rank takes part in the gathers, also one whose slice is empty
-                full = fl.round_sliced_gather(rows, self._client_weights(local_models), step_ws=ws)
-            # replicated plain means of the small entries (fedavg_aggregator.py:285-296)
-            for cls, key in ((MEAN_F32, "f32"), (MEAN_I64, "i64"), (MEAN_I32, "i32")):
-                cnt = lay.count[cls]
-                if not cnt:
-                    continue
-                xs = []
-                for model in local_models.values():
-                    parts = [model[e.name].detach().reshape(-1).to(e.dtype) for e in lay.entries if e.cls == cls]
-                    xs.append(torch.cat(parts).to(self.device))
-                self.ops.mean(xs, self._small[key], n=cnt)
-            out = self._assemble(full)
-            self._sync_model(self.model, out)
-            return out
+        if "_chunk_idx" in kwargs:
+            raise NotImplementedError("streamed (chunked) aggregation is not sharded; use the "
+                                      "single-GPU FedAvgAggregator for it")
+        return super().aggregate(local_models, **kwargs)

@@ -43,6 +43,8 @@ class Entry:
     cls: str
     offset: int        # element offset inside its class segment
     byte_offset: int   # byte offset inside a row
+    src_offset: int = 0    # first element of the client's tensor this entry covers
+    full_numel: int = -1   # elements of the client's whole tensor (-1: numel, the entry is whole)
 
 
 def classify(dtype: torch.dtype, is_parameter: bool) -> str:
@@ -122,6 +124,57 @@ class Layout:
             if t is None or tuple(t.shape) != e.shape or t.dtype != e.dtype:
                 return False
         return True
+
+
+class WindowedLayout(Layout):
+    """Row layout of a rank that owns only some ranges of the weighted (step) segment.
+
+    `windows` = (global_lo, global_hi, local_offset) triples: elements [global_lo, global_hi) of
+    the full layout's step segment live at [local_offset, ...) of this rank's step storage, which
+    is `storage` elements long (a multiple of 4; what lies beyond the windows is padding).  Rows
+    and state vectors keep the shape of :class:`Layout` -- ``[step storage | mean fp32 | ints]``
+    -- so the staging slab and the kernels work on them unchanged; `entries` holds one PIECE per
+    (step entry, window) intersection, so a name may appear more than once, and the plain-mean
+    entries whole (they are kept on every rank).  Name-based views belong to the full layout.
+    """
+
+    def __init__(self, full: Layout, windows: Sequence[Tuple[int, int, int]], storage: int):
+        if storage % 4:
+            raise ValueError("step storage must be a multiple of 4 elements (16 bytes)")
+        self.full = full
+        self.count = dict(full.count)
+        self.count[STEP] = storage
+        self.live_step = max((loc + hi - lo for lo, hi, loc in windows if hi > lo), default=0)
+        if self.live_step > storage:
+            raise ValueError("windows exceed the step storage")
+        self.n_f32 = storage + full.count[MEAN_F32]
+        self.seg_byte = {STEP: 0, MEAN_F32: 4 * storage}
+        self.seg_byte[MEAN_I64] = _round_up(4 * self.n_f32, 16)
+        self.seg_byte[MEAN_I32] = self.seg_byte[MEAN_I64] + 8 * self.count[MEAN_I64]
+        self.row_bytes = _round_up(self.seg_byte[MEAN_I32] + 4 * self.count[MEAN_I32], ROW_ALIGN)
+        self.entries = []
+        for e in full.entries:
+            if e.cls != STEP:
+                self.entries.append(Entry(e.name, e.shape, e.dtype, e.numel, e.cls, e.offset,
+                                          self.seg_byte[e.cls] + e.offset * _ITEMSIZE[e.cls]))
+                continue
+            for lo, hi, loc in windows:
+                a, b = max(e.offset, lo), min(e.offset + e.numel, hi)
+                if a < b:
+                    off = loc + a - lo
+                    self.entries.append(Entry(e.name, e.shape, e.dtype, b - a, STEP, off, 4 * off,
+                                              src_offset=a - e.offset, full_numel=e.numel))
+        self.by_name = {}
+        self.names = list(full.names)
+
+    def view(self, flats, name):
+        raise TypeError("a windowed layout has no per-name views; use the full layout")
+
+    def views(self, flats, classes=None):
+        raise TypeError("a windowed layout has no per-name views; use the full layout")
+
+    def matches(self, state):
+        return self.full.matches(state)
 
 
 def _numel(shape: Tuple[int, ...]) -> int:

@@ -1,51 +1,150 @@
 """Parameter-axis sharding of the FedAvg-family step over the GPUs of one node.
 
-Every element of the flat parameter vector is independent, so rank r of R (one process per GPU,
-`torch.distributed`, backend "nccl" = RCCL over xGMI) owns the contiguous slice
-``[r*L, (r+1)*L)`` of the vector padded to ``R*L`` with ``L`` a multiple of 4 (16 bytes).  The
-global model g, the moments m / v and FedBuff-style buffers live sharded and stay resident.
+Every element of the flat parameter vector is independent, so the vector is dealt to the R ranks
+(one process per GPU, `torch.distributed`, backend "nccl" = RCCL over xGMI) in BLOCKS: with
+``pieces`` blocks per rank of ``per`` elements each (a multiple of 4 = 16 bytes), block (p, r)
+holds the elements ``[(p*R + r)*per, (p*R + r + 1)*per)`` of the vector padded to
+``P = pieces*R*per``, and rank r stores its blocks back to back (``L = pieces*per`` elements).
+The point of dealing blocks instead of one contiguous slice per rank: the all-gather of block
+row p is ONE `all_gather_into_tensor` that lands in place, as the contiguous stretch
+``[p*R*per, (p+1)*R*per)`` of the gathered model -- no list outputs, no device-side reshuffle --
+so the gathers of the rows can be pipelined behind the kernels that produce them.  With
+``pieces = 1`` this is the plain contiguous split.  The global model g, the moments m / v and
+FedBuff-style buffers live sharded and stay resident.
 
 Two ways client updates reach the GPUs (no counterpart in the reference, whose server is one CPU
 process -- comm/mpi/mpi_server_communicator.py:56-90):
 
-* **sliced** -- slice r of every client update is on GPU r: one local fused kernel, no
-  collective; `all_gather_global()` (RCCL all-gather) only when every rank needs the whole model.
+* **sliced** -- rank r holds its blocks of every client update: one local fused kernel, no
+  collective in the arithmetic; the all-gather only hands every rank the whole new model.
   Bit-identical to the single-GPU result.
 * **whole**  -- whole client updates sit on different GPUs: each rank folds its clients into a
   full-length partial step against its copy of g, RCCL reduce-scatter (sum) leaves every rank
-  the step of its slice, the optimizer epilogue and the apply run on the slice, an all-gather
+  the step of its blocks, the optimizer epilogue and the apply run there, an all-gather
   refreshes the full g.  The cross-rank sum reorders the fp32 additions, so results agree with
   the single-GPU order to ~1e-7 relative, not bit for bit.
 
 `backend` is the module that provides the flat kernels (default: :mod:`appfl_amd.ops`, the HIP
-library).  Tests rehearse the collective logic on CPU with gloo by passing a stand-in backend.
+library).  It exists ONLY so the tests can rehearse the multi-rank logic on CPU with gloo by
+passing a stand-in; the product never passes it and has no CPU compute path.
 """
 
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
-
-def shard_length(n: int, world: int) -> int:
-    """Elements per rank: ceil(n / world) rounded up to a multiple of 4 (16 bytes)."""
-    per = (n + world - 1) // world
-    return (per + 3) // 4 * 4
+PIECE_BYTES = 128 << 20     # a block row is gathered on its own once a shard has several of these
+MAX_PIECES = 8
 
 
-def shard_bounds(n: int, world: int, rank: int):
-    """[lo, hi) of rank's slice inside the un-padded vector (hi - lo may be < shard_length)."""
-    L = shard_length(n, world)
-    lo = min(n, rank * L)
-    hi = min(n, lo + L)
-    return lo, hi
+def _round_up4(x: int) -> int:
+    return (x + 3) // 4 * 4
+
+
+def default_pieces(n: int, world: int) -> int:
+    """Blocks per rank: one per PIECE_BYTES of shard, 1..MAX_PIECES.  A function of (n, world)
+    only, so every rank derives the same value."""
+    shard_bytes = 4 * ((n + world - 1) // world)
+    return max(1, min(MAX_PIECES, shard_bytes // PIECE_BYTES))
+
+
+class ShardMap:
+    """Which elements of an n-element vector rank `rank` of `world` owns, and where."""
+
+    def __init__(self, n: int, world: int, rank: int, pieces: Optional[int] = None):
+        if n < 0 or world < 1 or not 0 <= rank < world:
+            raise ValueError("bad shard geometry")
+        self.n, self.world, self.rank = n, world, rank
+        self.pieces = default_pieces(n, world) if pieces is None else max(1, int(pieces))
+        self.per = max(4, _round_up4((n + world * self.pieces - 1) // (world * self.pieces)))
+        self.L = self.pieces * self.per          # elements of local storage
+        self.P = self.world * self.L             # elements of the padded gathered vector
+        self.n_local = sum(self.live(p) for p in range(self.pieces))
+
+    def block(self, p: int, rank: Optional[int] = None) -> Tuple[int, int]:
+        """[lo, hi) of block (p, rank) inside the un-padded vector (may be short or empty)."""
+        r = self.rank if rank is None else rank
+        lo = min(self.n, (p * self.world + r) * self.per)
+        return lo, min(self.n, lo + self.per)
+
+    def live(self, p: int, rank: Optional[int] = None) -> int:
+        lo, hi = self.block(p, rank)
+        return hi - lo
+
+    def windows(self, rank: Optional[int] = None) -> List[Tuple[int, int, int]]:
+        """(global_lo, global_hi, local_offset) of this rank's non-empty blocks.  Block starts
+        grow with p, so the live elements are a prefix [0, n_local) of the local storage."""
+        out = []
+        for p in range(self.pieces):
+            lo, hi = self.block(p, rank)
+            if hi > lo:
+                out.append((lo, hi, p * self.per))
+        return out
+
+    def row(self, p: int) -> Tuple[int, int]:
+        """[lo, hi) of block row p (all ranks' blocks p) inside the padded gathered vector."""
+        return p * self.world * self.per, (p + 1) * self.world * self.per
+
+    def take(self, full: torch.Tensor, rank: Optional[int] = None) -> torch.Tensor:
+        """This rank's local storage (L elements, zero padded) cut out of a full-length vector."""
+        out = torch.zeros(self.L, dtype=full.dtype, device=full.device)
+        for lo, hi, loc in self.windows(rank):
+            out[loc:loc + hi - lo].copy_(full[lo:hi])
+        return out
+
+
+def _shift(x, elements: int):
+    """Client buffer `x` (device tensor, or a raw device address the caller vouches for) advanced
+    by `elements` fp32 elements."""
+    return x + 4 * elements if isinstance(x, int) else x[elements:]
+
+
+def gather_rows(smap: ShardMap, g: torch.Tensor, out: torch.Tensor, group=None,
+                rows: Optional[Sequence[int]] = None, async_op: bool = False):
+    """All-gather of block rows of the sharded vector `g` (L elements) into the padded full
+    vector `out` (P elements): one `all_gather_into_tensor` per row, landing in place."""
+    works = []
+    for p in (range(smap.pieces) if rows is None else rows):
+        a, b = smap.row(p)
+        src = g[p * smap.per:(p + 1) * smap.per]
+        if smap.world == 1:
+            out[a:b].copy_(src)
+        else:
+            w = dist.all_gather_into_tensor(out[a:b], src, group=group, async_op=async_op)
+            if async_op:
+                works.append(w)
+    return works
+
+
+def round_gather_pipelined(ops, smap: ShardMap, x: Sequence, w: Sequence[float], g, m, v, opt: str,
+                           hp: dict, out: torch.Tensor, group=None, step_ws=None) -> torch.Tensor:
+    """The sliced round followed by the all-gather of the new model, pipelined over the block
+    rows: the fused kernel runs on block p, then its row's all-gather is enqueued (RCCL works
+    on its own stream) while the kernel of block p+1 runs.  Every rank enqueues every gather,
+    also for rows in which its own block is empty.  On xGMI the gather of a large model takes
+    about as long as the local round, so the pipeline hides whichever is shorter."""
+    if out.numel() < smap.P:
+        raise ValueError("gather buffer shorter than the padded vector")
+    works = []
+    for p in range(smap.pieces):
+        a, live = p * smap.per, smap.live(p)
+        if live > 0:
+            ops.reduce_opt([_shift(c, a) for c in x], list(w), g[a:],
+                           None if m is None else m[a:], None if v is None else v[a:], opt,
+                           step_ws=None if step_ws is None else step_ws[a:], n=live, **hp)
+        works += gather_rows(smap, g, out, group, rows=[p], async_op=True)
+    for wk in works:
+        wk.wait()
+    return out
 
 
 class ShardedFlatAggregator:
     def __init__(self, n: int, opt: str = "none", lr: float = 0.0, beta1: float = 0.0,
-                 beta2: float = 0.0, tau: float = 0.0, device=None, group=None, backend=None):
+                 beta2: float = 0.0, tau: float = 0.0, device=None, group=None, backend=None,
+                 pieces: Optional[int] = None):
         if backend is None:
             from . import ops as backend   # HIP kernels; raises if the library is not built
         self.ops = backend
@@ -53,8 +152,8 @@ class ShardedFlatAggregator:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n = n
-        self.L = shard_length(n, self.world)
-        self.lo, self.hi = shard_bounds(n, self.world, self.rank)
+        self.map = ShardMap(n, self.world, self.rank, pieces)
+        self.L = self.map.L
         self.opt = opt
         self.hp = dict(lr=lr, beta1=beta1, beta2=beta2, tau=tau)
         if device is None:
@@ -77,96 +176,89 @@ class ShardedFlatAggregator:
         """Install a full-length global vector (every rank passes the same values)."""
         if g_full.numel() != self.n:
             raise ValueError(f"expected {self.n} elements, got {g_full.numel()}")
-        self.g.zero_()
-        self.g[: self.hi - self.lo].copy_(g_full[self.lo:self.hi])
+        self.g.copy_(self.map.take(g_full.to(self.device)))
         if self.g_full is not None:
             self.g_full[: self.n].copy_(g_full)
+
+    def new_gather_buffer(self) -> torch.Tensor:
+        return torch.zeros(self.map.P, dtype=torch.float32, device=self.device)
 
     def all_gather_global(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """RCCL all-gather of the shards: the padded full vector (first n elements are g)."""
         if out is None:
-            out = torch.empty(self.world * self.L, dtype=torch.float32, device=self.device)
-        if self.world == 1:
-            out.copy_(self.g)
-        else:
-            dist.all_gather_into_tensor(out, self.g, group=self.group)
+            out = self.new_gather_buffer()
+        gather_rows(self.map, self.g, out, self.group)
         return out
 
     # -- sliced mode ------------------------------------------------------------------------
-    def round_sliced(self, client_slices: Sequence[torch.Tensor], weights: Sequence[float],
+    def round_sliced(self, client_slices: Sequence, weights: Sequence[float],
                      step_ws: Optional[torch.Tensor] = None) -> None:
-        """One round on this rank's slice: `client_slices[k]` holds elements [lo, hi) of client
-        k's update (at least hi - lo elements).  No collective."""
-        n_local = self.hi - self.lo
+        """One round on this rank's blocks: `client_slices[k]` holds client k's update in this
+        rank's local storage order (`ShardMap.take`; at least n_local elements).  No collective."""
+        n_local = self.map.n_local
         if n_local == 0:
             return
         self.ops.reduce_opt(list(client_slices), list(weights), self.g, self.m, self.v, self.opt,
                             step_ws=step_ws, n=n_local, **self.hp)
 
-    def round_sliced_gather(self, client_slices: Sequence[torch.Tensor], weights: Sequence[float],
-                            out: Optional[torch.Tensor] = None, pieces: int = 4,
+    def round_sliced_gather(self, client_slices: Sequence, weights: Sequence[float],
+                            out: Optional[torch.Tensor] = None,
                             step_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """`round_sliced` followed by the all-gather of the new global model, pipelined: the
-        slice is aggregated in `pieces` pieces and the all-gather of piece p runs (on RCCL's own
-        stream) while piece p+1 is being aggregated.  On xGMI the gather of a large model takes
-        several times longer than the local round, so this hides the round, not the gather.
-        Returns the padded full vector (rank r's slice at [r*L, (r+1)*L))."""
+        """`round_sliced` + the all-gather of the new global model, pipelined over the block
+        rows (`round_gather_pipelined`).  Returns the padded full vector."""
         if out is None:
-            out = torch.empty(self.world * self.L, dtype=torch.float32, device=self.device)
-        if out.numel() < self.world * self.L:
-            raise ValueError("gather buffer shorter than world * shard_length")
-        n_local = self.hi - self.lo
-        pieces = max(1, min(int(pieces), self.L // 4 or 1))
-        per = ((self.L + pieces - 1) // pieces + 3) // 4 * 4
-        works = []
-        for a in range(0, self.L, per):
-            b = min(self.L, a + per)
-            live = min(b, n_local) - a          # elements of this piece that hold parameters
-            if live > 0:
-                self.ops.reduce_opt([c[a:] for c in client_slices], list(weights), self.g[a:],
-                                    None if self.m is None else self.m[a:],
-                                    None if self.v is None else self.v[a:], self.opt,
-                                    step_ws=None if step_ws is None else step_ws[a:], n=live,
-                                    **self.hp)
-            if self.world == 1:
-                out[a:b].copy_(self.g[a:b])
-            else:
-                dst = [out[r * self.L + a:r * self.L + b] for r in range(self.world)]
-                works.append(dist.all_gather(dst, self.g[a:b], group=self.group, async_op=True))
-        for w in works:
-            w.wait()
-        return out
+            out = self.new_gather_buffer()
+        return round_gather_pipelined(self.ops, self.map, client_slices, weights, self.g, self.m,
+                                      self.v, self.opt, self.hp, out, self.group, step_ws)
 
     # -- whole-update mode ------------------------------------------------------------------
-    def _reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+    def _reduce_scatter_row(self, p: int):
+        """Sum over ranks of block row p of the partial step; this rank keeps its block."""
+        a, b = self.map.row(p)
+        dst = self._step[p * self.map.per:(p + 1) * self.map.per]
         if self.world == 1:
-            out.copy_(inp)
-        elif dist.get_backend(self.group) == "gloo":
-            # gloo has no reduce-scatter; CPU rehearsals all-reduce and keep the local slice
-            dist.all_reduce(inp, group=self.group)
-            out.copy_(inp[self.rank * self.L:(self.rank + 1) * self.L])
-        else:
-            dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=self.group)
+            dst.copy_(self._partial[a:b])
+            return None
+        if dist.get_backend(self.group) == "gloo":
+            # gloo has no reduce-scatter; CPU rehearsals all-reduce the row and keep their block
+            dist.all_reduce(self._partial[a:b], group=self.group)
+            dst.copy_(self._partial[a + self.rank * self.map.per:a + (self.rank + 1) * self.map.per])
+            return None
+        return dist.reduce_scatter_tensor(dst, self._partial[a:b], op=dist.ReduceOp.SUM,
+                                          group=self.group, async_op=True)
 
     def round_whole(self, my_clients: Sequence[torch.Tensor], my_weights: Sequence[float]) -> None:
         """One round where this rank holds whole updates of SOME clients (`my_clients[k]` has n
-        elements; `my_weights` are their global weights; a rank may hold none).  Partial step
-        against the replicated g, reduce-scatter, optimizer + apply on the slice, all-gather."""
-        P = self.world * self.L
+        elements; `my_weights` are their global weights; a rank may hold none).  Per block row:
+        partial step against the replicated g, reduce-scatter; then optimizer + apply on the
+        own block and the all-gather of the row -- both collectives pipelined behind the
+        kernels of the next row."""
+        smap = self.map
         if self.g_full is None:
             self.g_full = self.all_gather_global()
         if self._partial is None:
-            self._partial = torch.zeros(P, dtype=torch.float32, device=self.device)
+            self._partial = torch.zeros(smap.P, dtype=torch.float32, device=self.device)
             self._step = torch.zeros(self.L, dtype=torch.float32, device=self.device)
-        if len(my_clients):
-            self.ops.reduce_step(list(my_clients), list(my_weights), self.g_full, self._partial,
-                                 n=self.n)
-        else:
+        scatters = []
+        if not len(my_clients):
             self._partial.zero_()
-        self._reduce_scatter(self._step, self._partial)
-        n_local = self.hi - self.lo
-        if n_local:
-            if self.opt != "none":
-                self.ops.server_opt_step(self._step, self.m, self.v, self.opt, n=n_local, **self.hp)
-            self.ops.apply_step(self.g, self._step, n=n_local)
-        self.all_gather_global(self.g_full)
+        for p in range(smap.pieces):
+            a, b = smap.row(p)
+            b = min(b, self.n)
+            if len(my_clients) and b > a:
+                self.ops.reduce_step([_shift(c, a) for c in my_clients], list(my_weights),
+                                     self.g_full[a:], self._partial[a:], n=b - a)
+            scatters.append(self._reduce_scatter_row(p))
+        gathers = []
+        for p in range(smap.pieces):
+            if scatters[p] is not None:
+                scatters[p].wait()
+            a, live = p * smap.per, smap.live(p)
+            if live:
+                if self.opt != "none":
+                    self.ops.server_opt_step(self._step[a:], None if self.m is None else self.m[a:],
+                                             self.v[a:], self.opt, n=live, **self.hp)
+                self.ops.apply_step(self.g[a:], self._step[a:], n=live)
+            gathers += gather_rows(smap, self.g, self.g_full, self.group, rows=[p], async_op=True)
+        for wk in gathers:
+            wk.wait()

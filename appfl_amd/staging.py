@@ -10,6 +10,7 @@ tensors and hands them to the aggregator (agent/server.py:505-525, sync_schedule
 from __future__ import annotations
 
 import collections
+import contextlib
 import ctypes as C
 import weakref
 from typing import Dict, List, Optional
@@ -24,18 +25,24 @@ UPLOAD_WINDOW = 32 << 20
 
 
 class ClientSlab:
+    """K client rows in device memory.  With `device` = cpu (multi-rank rehearsals of the sharded
+    aggregator on a machine without a GPU) the slab is host memory and every copy is immediate;
+    nothing is computed here either way."""
+
     def __init__(self, layout: Layout, device: torch.device, slots: int = 3):
         self.layout = layout
-        self.device = device
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
         self.row_bytes = layout.row_bytes
         self.capacity = 0
         self.slab: Optional[torch.Tensor] = None
         self.nslots = slots
-        self.pinned = torch.empty((slots, self.row_bytes), dtype=torch.uint8, pin_memory=True)
-        self.copy_stream = torch.cuda.Stream(device=device)
+        self.pinned = torch.empty((slots, self.row_bytes), dtype=torch.uint8, pin_memory=self.on_gpu)
+        self.copy_stream = torch.cuda.Stream(device=device) if self.on_gpu else None
         self.slot_free = [None] * slots   # event recorded after the slot's last H2D copy
         self.next_slot = 0
         self.last_copy: Optional[torch.cuda.Event] = None
+        self.has_device_sources = False   # the last upload read device tensors of the caller
 
     def reserve(self, rows: int, preserve: int = 0) -> None:
         """Room for `rows` client rows; the first `preserve` rows keep their contents when the
@@ -45,22 +52,35 @@ class ClientSlab:
         if preserve:
             rows = max(rows, 2 * self.capacity)
         need = rows * self.row_bytes
-        free, _ = torch.cuda.mem_get_info(self.device)
-        have = 0 if (self.slab is None or preserve) else self.slab.numel()
-        if need - have > free:
-            raise MemoryError(
-                f"staging {rows} client updates needs {need / 2**30:.1f} GiB of device memory, "
-                f"{free / 2**30:.1f} GiB free")
-        # kernels of earlier rounds may still read the old slab on the compute stream
-        torch.cuda.current_stream(self.device).synchronize()
-        self.copy_stream.synchronize()
+        if self.on_gpu:
+            free, _ = torch.cuda.mem_get_info(self.device)
+            have = 0 if (self.slab is None or preserve) else self.slab.numel()
+            if need - have > free:
+                raise MemoryError(
+                    f"staging {rows} client updates needs {need / 2**30:.1f} GiB of device memory, "
+                    f"{free / 2**30:.1f} GiB free")
+            # kernels of earlier rounds may still read the old slab on the compute stream
+            torch.cuda.current_stream(self.device).synchronize()
+            self.copy_stream.synchronize()
         old = self.slab if preserve else None
         self.slab = None
         self.slab = torch.empty((rows, self.row_bytes), dtype=torch.uint8, device=self.device)
         if old is not None:
             self.slab[:preserve].copy_(old[:preserve])
-            torch.cuda.current_stream(self.device).synchronize()
+            if self.on_gpu:
+                torch.cuda.current_stream(self.device).synchronize()
         self.capacity = rows
+
+    def _on_copy_stream(self):
+        return torch.cuda.stream(self.copy_stream) if self.on_gpu else contextlib.nullcontext()
+
+    def _copy_event(self):
+        """Event after everything enqueued on the copy stream so far (None on a CPU slab)."""
+        if not self.on_gpu:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.copy_stream)
+        return ev
 
     def row_ptr(self, k: int) -> int:
         return self.slab.data_ptr() + k * self.row_bytes
@@ -71,7 +91,8 @@ class ClientSlab:
 
     def begin_round(self) -> None:
         """Order this round's uploads after the kernels that read the slab last round."""
-        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        if self.on_gpu:
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def upload(self, k: int, state: Dict[str, torch.Tensor], fill_missing_from=None,
                on_window=None) -> None:
@@ -85,29 +106,32 @@ class ClientSlab:
         host_src: List[int] = []
         host_off: List[int] = []
         host_len: List[int] = []
-        keep = []          # converted tensors must outlive the memcpy
+        keep = {}          # name -> converted tensor; must outlive the memcpy / the queued copies
         dev_items = []
         missing = []
-        for e in lay.entries:
-            t = state.get(e.name)
+        for e in lay.entries:          # a windowed layout lists one piece per (entry, window)
+            t = keep.get(e.name)
             if t is None:
-                if e.cls != "step":
-                    raise KeyError(e.name)
-                missing.append(e)
-                continue
-            if t.numel() != e.numel:
-                raise ValueError(f"{e.name}: client tensor has {t.numel()} elements, "
-                                 f"global state has {e.numel}")
-            if t.dtype != e.dtype:
-                t = t.to(e.dtype)
-            if not t.is_contiguous():
-                t = t.contiguous()
+                t = state.get(e.name)
+                if t is None:
+                    if e.cls != "step":
+                        raise KeyError(e.name)
+                    missing.append(e)
+                    continue
+                full = e.numel if e.full_numel < 0 else e.full_numel
+                if t.numel() != full:
+                    raise ValueError(f"{e.name}: client tensor has {t.numel()} elements, "
+                                     f"global state has {full}")
+                if t.dtype != e.dtype:
+                    t = t.to(e.dtype)
+                if not t.is_contiguous():
+                    t = t.contiguous()
+                keep[e.name] = t
             if t.is_cuda:
                 dev_items.append((e, t))
                 continue
-            keep.append(t)
             if e.numel:
-                host_src.append(t.data_ptr())
+                host_src.append(t.data_ptr() + e.src_offset * t.element_size())
                 host_off.append(e.byte_offset)
                 host_len.append(e.numel * t.element_size())
         slot = self.next_slot
@@ -115,7 +139,7 @@ class ClientSlab:
         if self.slot_free[slot] is not None:
             self.slot_free[slot].synchronize()
         T = len(host_src)
-        if dev_items or missing:
+        if self.on_gpu and (dev_items or missing):
             # device-side sources may still be being written on the caller's stream
             self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         if T:
@@ -129,26 +153,35 @@ class ClientSlab:
                 rc = lib.fa_pack_host_window(C.c_void_p(pinned.data_ptr()), srcs, offs, lens, T,
                                              a, b, PACK_THREADS)
                 N.check(rc, "fa_pack_host_window")
-                with torch.cuda.stream(self.copy_stream):
+                with self._on_copy_stream():
                     self.slab[k, a:b].copy_(pinned[a:b], non_blocking=True)
-                    if on_window is not None:
-                        landed = torch.cuda.Event()
-                        landed.record(self.copy_stream)
+                    landed = self._copy_event() if on_window is not None else None
                 if on_window is not None:
                     # lets the caller start work on bytes [a, b) of the row once `landed` fires
                     on_window(a, b, landed)
-        with torch.cuda.stream(self.copy_stream):
+        with self._on_copy_stream():
             for e, t in dev_items:
-                self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(t.view(-1), non_blocking=True)
+                src = t.view(-1)[e.src_offset:e.src_offset + e.numel]
+                self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(src, non_blocking=True)
+                if self.on_gpu:
+                    # the source (possibly a temporary made above on the caller's stream) must not
+                    # be handed out again by the allocator before this queued copy has run
+                    t.record_stream(self.copy_stream)
             for e in missing:
                 off = lay.flat_offset(e)
                 self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(
                     fill_missing_from[off:off + e.numel], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy_stream)
+            ev = self._copy_event()
         self.slot_free[slot] = ev
         self.last_copy = ev
+        self.has_device_sources = bool(dev_items)
         del keep
+
+    def wait_uploads(self) -> None:
+        """Blocks the host until every upload enqueued so far has landed (a caller that hands in
+        device tensors may overwrite them once this returns)."""
+        if self.last_copy is not None:
+            self.last_copy.synchronize()
 
     def end_round(self) -> None:
         """Make the compute stream wait for every upload of this round."""
@@ -217,6 +250,8 @@ class HostDownloader:
     def fetch(self, flat: torch.Tensor, n: int) -> torch.Tensor:
         if n == 0:
             return torch.empty(0, dtype=flat.dtype)
+        if not flat.is_cuda:           # CPU rehearsal of the sharded aggregator: already host memory
+            return flat[:n].clone()
         item = flat.element_size()
         lease = self._pool.lease(n * item) if self._pool is not None else None
         if lease is not None:
@@ -226,6 +261,26 @@ class HostDownloader:
             torch.cuda.current_stream(flat.device).synchronize()
             return out
         return self._fetch_pageable(flat, n)
+
+    def fetch_parts(self, parts: List[torch.Tensor]) -> torch.Tensor:
+        """One fresh host tensor holding the concatenation of `parts` (1-D device tensors of one
+        dtype, e.g. the blocks of a gathered model): every part is its own D2H copy into its
+        place in one leased pinned buffer."""
+        parts = [p for p in parts if p.numel()]
+        if not parts:
+            return torch.empty(0, dtype=torch.float32)
+        n = sum(p.numel() for p in parts)
+        if not parts[0].is_cuda:
+            return torch.cat([p.reshape(-1) for p in parts]).clone()
+        out = self.lease(parts[0].dtype, n)
+        if out is None:
+            return self._fetch_pageable(torch.cat(parts), n)
+        pos = 0
+        for p in parts:
+            out[pos:pos + p.numel()].copy_(p, non_blocking=True)
+            pos += p.numel()
+        torch.cuda.current_stream(parts[0].device).synchronize()
+        return out
 
     def lease(self, dtype: torch.dtype, n: int) -> Optional[torch.Tensor]:
         """An n-element result tensor on a leased pinned buffer for a caller that fills it

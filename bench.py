@@ -7,10 +7,18 @@ resident in HBM: for the FedAvg family one round (the fused weighted-step / serv
 apply kernel over the K staged client rows plus the small plain-mean kernels), for FedAsync /
 FedBuff one arrival.  `value` = client-update bytes consumed per second over all ranks.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the parameter axis is sharded, every
-rank owns a shard of the workload's size and aggregates it with no data-path collective (weak
-scaling); `--allgather` additionally times the round with an RCCL all-gather of the updated
-shards and reports it under "allgather".
+N = 1: the headline workload (ResNet-18 FedAvg, K = 100) is timed as `value`; the other
+benchmark configurations are measured in the same process and listed under "workloads" (kernel
+time from events on the launch stream, roofline fraction), the north-star target configuration
+under "north_star_target", the PCIe-inclusive aggregate() under "end_to_end", and the whole
+1.3 B-parameter K = 32 round on this one GPU under "strong_scaling_reference".
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling of the 1.3 B-parameter
+K = 32 FedAvg round (or of --workload's flat vector): the parameter axis is dealt to the ranks in
+blocks (appfl_amd.sharded.ShardMap), every rank aggregates its blocks of every client update and
+RCCL all-gathers hand every rank the whole new model.  `value` times the product path
+(`round_sliced_gather`: kernels and gathers pipelined over the block rows); "no_collective",
+"allgather" (round, then gather) and "allgather_pipelined" report the three forms side by side.
 
 Prints ONE JSON line on rank 0.
 """
@@ -33,6 +41,12 @@ import torch.distributed as dist
 METRIC = "device-resident FedAvg aggregation GB/s (K clients x params), % HBM peak"
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (datasheet)
 DEFAULT_WORKLOAD = "resnet18_fedavg_k100"
+SHARDED_WORKLOAD = "flat1300m_fedavg_k32"
+NORTH_STAR_WORKLOAD = "resnet50_fedadam_k64"
+EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "flat162m_fedavg_k32",
+                   "vitb16_fedasync", "vitb16_fedbuff_k16"]
+_OPT_OF = {"FedAvgAggregator": "none", "FedAvgMAggregator": "avgm", "FedAdamAggregator": "adam",
+           "FedYogiAggregator": "yogi", "FedAdagradAggregator": "adagrad"}
 STATE_VECTORS = {"none": 2, "avgm": 4, "adam": 6, "yogi": 6, "adagrad": 6}  # g/m/v reads + writes
 
 
@@ -41,14 +55,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
+    ap.add_argument("--workload", default=None,
+                    help=f"default: {DEFAULT_WORKLOAD} on one GPU, {SHARDED_WORKLOAD} sharded on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allgather", action="store_true",
-                    help="also time the round followed by an all-gather of the updated shards")
+    ap.add_argument("--only", action="store_true",
+                    help="one GPU: time the chosen workload only (no extra workloads, no end-to-end)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="run the block-dealt multi-GPU form also on one rank (rehearsal)")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-big", action="store_true",
+                    help="one GPU: skip the 166 GB strong-scaling reference run")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU time budget of each cpu_baseline leg")
-    ap.add_argument("--end-to-end", action="store_true",
-                    help="also time aggregate() from CPU state dicts to a CPU state dict (PCIe included)")
     return ap.parse_args()
 
 
@@ -88,18 +106,6 @@ class SyncBench:
 
     def step(self, events=None):
         self.agg._launch_round(self.K, self.weights, True, events)
-
-    def step_piece(self, lo, hi):
-        """The fused round restricted to elements [lo, hi) of the step segment (lo % 4 == 0)."""
-        slab, lay, g = self.agg._slab, self.agg._layout, self.agg._flats["f32"]
-        hi = min(hi, self.n_step)
-        if hi <= lo:
-            return
-        rows = [slab.row_ptr(k) + 4 * lo for k in range(self.K)]
-        self.agg._ensure_moments()
-        m, v = self.agg._m, self.agg._v
-        self.ops.reduce_opt(rows, self.weights, g[lo:], None if m is None else m[lo:],
-                            None if v is None else v[lo:], self.opt, n=hi - lo, **self.agg._hyper())
 
     def result(self):
         return self.agg._flats["f32"][:self.result_numel]
@@ -305,6 +311,113 @@ def end_to_end(wl, rounds=4):
                     "median of rounds 2.."}
 
 
+class ShardedBench:
+    """The flat vector of a FedAvg-family workload dealt to the ranks in blocks; K synthetic
+    client rows per rank, generated on the device so that the ranks' blocks are pieces of ONE
+    consistent set of client vectors."""
+
+    def __init__(self, wl, world, rank):
+        from appfl_amd import ops, workloads as W
+        from appfl_amd.sharded import ShardedFlatAggregator
+        self.ops = ops
+        rows = wl["table"]()
+        self.n_total = W.numel([r for r in rows if r[2] == torch.float32 and r[3]])
+        self.K = wl["K"]
+        self.opt = _OPT_OF[wl["cls"]]
+        cfg = W.EXAMPLE_CONFIGS[wl["cls"]]
+        hp = dict(lr=cfg.get("server_learning_rate", 0.0), tau=cfg.get("server_adapt_param", 0.0),
+                  beta1=cfg.get("server_momentum_param_1", 0.0),
+                  beta2=cfg.get("server_momentum_param_2", 0.0))
+        self.agg = ShardedFlatAggregator(self.n_total, self.opt, **hp)
+        smap = self.map = self.agg.map
+        g = self.agg.g
+        self.slab = torch.zeros((self.K, smap.L), dtype=torch.float32, device=g.device)
+        for lo, hi, loc in smap.windows():
+            ops.synth_fill(g[loc:], 7, first=lo, scale=0.05, n=hi - lo)
+            for k in range(self.K):
+                ops.synth_fill(self.slab[k, loc:], 1000 + k, first=lo, scale=0.01, base=g[loc:],
+                               n=hi - lo)
+        self.rows = [self.slab[k] for k in range(self.K)]
+        self.weights = [1.0 / self.K] * self.K
+        self.out = self.agg.new_gather_buffer()
+        self.kernel = "%s<%s>" % (ops.reduce_kernel_name(self.K, max(smap.n_local, 1), self.opt), self.opt)
+        self.alg_bytes = 4 * (self.K + STATE_VECTORS[self.opt]) * smap.n_local
+        self.client_bytes = 4 * self.K * smap.n_local          # this rank's share of the client bytes
+
+    def step_local(self, events=None):
+        if events:
+            events[0].record()
+        self.agg.round_sliced(self.rows, self.weights)
+        if events:
+            events[1].record()
+
+    def step_gather(self, events=None):
+        self.agg.round_sliced(self.rows, self.weights)
+        self.agg.all_gather_global(self.out)
+
+    def step_pipelined(self, events=None):
+        self.agg.round_sliced_gather(self.rows, self.weights, self.out)
+
+
+def time_steps(step, steps, warmup, barrier, use_dist, with_events=True):
+    """`warmup` untimed steps, then `steps` steps between barriers; returns (seconds -- the max
+    over ranks --, sorted per-step kernel ms from events on the launch stream)."""
+    for _ in range(warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(steps)] if with_events else [None] * steps
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(evs[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs) if with_events else []
+    return elapsed, kernel_ms
+
+
+def roofline_of(b, kernel_ms, workload):
+    avg = sum(kernel_ms) / len(kernel_ms)
+    achieved = b.alg_bytes / (avg * 1e-3) / 1e9
+    traffic, source = None, None
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get(workload, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+        if traffic is not None:
+            source = ("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this workload recorded "
+                      "earlier (2*FETCH_SIZE + WRITE_SIZE per launch), not measured in this run")
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+            "kernel": b.kernel, "kernel_avg_ms": round(avg, 5), "kernel_min_ms": round(kernel_ms[0], 5),
+            "algorithmic_bytes_per_launch": int(b.alg_bytes)}
+
+
+def measure_workload(name, steps, warmup, barrier):
+    """One extra workload on this GPU: same timing as the headline, its objects freed after."""
+    from appfl_amd import workloads as W
+    wl = W.WORKLOADS[name]
+    is_async = wl["cls"] in ("FedAsyncAggregator", "FedBuffAggregator")
+    b = (AsyncBench if is_async else SyncBench)(wl, 0)
+    elapsed, kernel_ms = time_steps(b.step, steps, warmup, barrier, False)
+    r = roofline_of(b, kernel_ms, name)
+    out = {"workload": name, "aggregator": wl["cls"], "clients": wl["K"], "steps": steps,
+           "value": round(b.client_bytes * steps / elapsed / 1e9, 2), "unit": "GB/s",
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "kernel": r["kernel"],
+           "kernel_avg_ms": r["kernel_avg_ms"], "kernel_min_ms": r["kernel_min_ms"],
+           "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+           "achieved": r["achieved"], "frac": r["frac"], "traffic": r["traffic"]}
+    del b
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -319,11 +432,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from appfl_amd import workloads as W
-    if a.workload not in W.WORKLOADS:
-        raise SystemExit(f"unknown workload {a.workload}; choose from {sorted(W.WORKLOADS)}")
-    wl = W.WORKLOADS[a.workload]
+    sharded = world > 1 or a.sharded
+    name = a.workload or (SHARDED_WORKLOAD if sharded else DEFAULT_WORKLOAD)
+    if name not in W.WORKLOADS:
+        raise SystemExit(f"unknown workload {name}; choose from {sorted(W.WORKLOADS)}")
+    wl = W.WORKLOADS[name]
     is_async = wl["cls"] in ("FedAsyncAggregator", "FedBuffAggregator")
-    b = (AsyncBench if is_async else SyncBench)(wl, rank)
+    if sharded and is_async:
+        raise SystemExit("the sharded benchmark takes a FedAvg-family workload")
 
     def barrier():
         torch.cuda.synchronize()
@@ -331,84 +447,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        b.step()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(a.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        b.step(evs[i])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    if sharded:
+        b = ShardedBench(wl, world, rank)
+        # value: the product path (kernels and gathers pipelined over the block rows)
+        elapsed, _ = time_steps(b.step_pipelined, a.steps, a.warmup, barrier, use_dist, False)
+        el_seq, _ = time_steps(b.step_gather, a.steps, 2, barrier, use_dist, False)
+        el_loc, kernel_ms = time_steps(b.step_local, a.steps, 2, barrier, use_dist)
+        total_client = torch.tensor([b.client_bytes], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(total_client)
+        total_client = float(total_client.item())
 
-    extra = {}
-    if a.allgather and use_dist:
-        shard = b.result()
-        full = torch.empty(world * shard.numel(), dtype=shard.dtype, device=shard.device)
-        for _ in range(2):
-            b.step()
-            dist.all_gather_into_tensor(full, shard)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            b.step()
-            dist.all_gather_into_tensor(full, shard)
-        barrier()
-        el2 = time.perf_counter() - t0
-        t = torch.tensor([el2], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = float(t.item())
-        extra["allgather"] = {"value": round(world * b.client_bytes * a.steps / el2 / 1e9, 2),
-                              "unit": "GB/s", "ms_per_step": round(el2 / a.steps * 1e3, 4),
-                              "gathered_bytes_per_rank": world * shard.numel() * 4}
-        if hasattr(b, "step_piece"):
-            # the same, pipelined: the gather of piece p overlaps the aggregation of piece p+1
-            pieces = 4
-            n = shard.numel()
-            per = ((n + pieces - 1) // pieces + 3) // 4 * 4
-            full = torch.empty(world * n, dtype=shard.dtype, device=shard.device)
+        def form(el):
+            return {"value": round(total_client * a.steps / el / 1e9, 2), "unit": "GB/s",
+                    "ms_per_step": round(el / a.steps * 1e3, 4)}
+        if rank == 0:
+            out = {
+                "metric": METRIC, **form(elapsed), "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": name, "aggregator": wl["cls"], "clients": wl["K"],
+                           "params_total": b.n_total, "params_per_gpu": b.map.n_local,
+                           "client_bytes_per_step_total": int(total_client),
+                           "block_rows": b.map.pieces, "block_elements": b.map.per,
+                           "gathered_bytes_per_gpu": 4 * b.map.P,
+                           "parallelism": f"parameter axis dealt in blocks to {world} GPUs; fused "
+                                          "kernel per block row, RCCL all_gather_into_tensor per row, "
+                                          "pipelined (value); N=1 counterpart of this workload: "
+                                          "strong_scaling_reference of the one-GPU line"},
+                "no_collective": form(el_loc),
+                "allgather": form(el_seq),
+                "allgather_pipelined": form(elapsed),
+                "roofline": roofline_of(b, kernel_ms, name),
+            }
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
-            def pipelined():
-                works = []
-                for lo in range(0, n, per):
-                    hi = min(n, lo + per)
-                    b.step_piece(lo, hi)
-                    dst = [full[r * n + lo:r * n + hi] for r in range(world)]
-                    works.append(dist.all_gather(dst, shard[lo:hi], async_op=True))
-                for w in works:
-                    w.wait()
-
-            for _ in range(2):
-                pipelined()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(a.steps):
-                pipelined()
-            barrier()
-            el3 = time.perf_counter() - t0
-            t = torch.tensor([el3], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el3 = float(t.item())
-            extra["allgather_pipelined"] = {
-                "value": round(world * b.client_bytes * a.steps / el3 / 1e9, 2), "unit": "GB/s",
-                "ms_per_step": round(el3 / a.steps * 1e3, 4), "pieces": pieces}
-
+    b = (AsyncBench if is_async else SyncBench)(wl, rank)
+    elapsed, kernel_ms = time_steps(b.step, a.steps, a.warmup, barrier, use_dist)
     if rank == 0:
-        achieved = b.alg_bytes / (kernel_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get(a.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": METRIC,
             "value": round(world * b.client_bytes * a.steps / elapsed / 1e9, 2),
@@ -422,21 +501,35 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": a.workload, "aggregator": wl["cls"], "clients": wl["K"],
+            "config": {"workload": name, "aggregator": wl["cls"], "clients": wl["K"],
                        "params_per_gpu": b.result_numel, "client_bytes_per_step_per_gpu": b.client_bytes,
-                       "parallelism": f"param-shard x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": b.kernel, "kernel_avg_ms": round(kernel_avg_ms, 5),
-                         "kernel_min_ms": round(kernel_ms[0], 5),
-                         "algorithmic_bytes_per_launch": int(b.alg_bytes)},
+                       "parallelism": "one GPU"},
+            "roofline": roofline_of(b, kernel_ms, name),
         }
-        out.update(extra)
-        if world == 1 and a.end_to_end and not is_async:
-            out["end_to_end"] = end_to_end(wl)
-        if world == 1 and not a.no_cpu_baseline:
-            del b
-            torch.cuda.empty_cache()
+        del b
+        torch.cuda.empty_cache()
+        if not a.only:
+            extra = []
+            for other in EXTRA_WORKLOADS:
+                if other != name:
+                    extra.append(measure_workload(other, a.steps, a.warmup, barrier))
+            out["workloads"] = extra
+            target = next((w for w in extra if w["workload"] == NORTH_STAR_WORKLOAD), None)
+            if target is not None:
+                out["north_star_target"] = {"workload": NORTH_STAR_WORKLOAD, "frac": target["frac"],
+                                            "kernel_avg_ms": target["kernel_avg_ms"],
+                                            "value": target["value"], "unit": "GB/s"}
+            if not a.no_big:
+                try:
+                    out["strong_scaling_reference"] = measure_workload(
+                        SHARDED_WORKLOAD, max(3, a.steps // 5), 2, barrier)
+                except (RuntimeError, MemoryError) as e:      # not enough free HBM on this box
+                    out["strong_scaling_reference"] = {"workload": SHARDED_WORKLOAD,
+                                                       "skipped": str(e)[:200]}
+                    torch.cuda.empty_cache()
+            if not a.no_end_to_end and not is_async:
+                out["end_to_end"] = end_to_end(wl)
+        if not a.no_cpu_baseline:
             naive, fused = cpu_baseline(wl, a.cpu_seconds)
             out["cpu_baseline"] = naive
             out["cpu_baseline_fused"] = fused

@@ -1,0 +1,61 @@
+"""bench.py end to end on the GPU: the one-GPU line and, through torch.distributed.run with ONE
+nccl rank, the block-dealt multi-GPU form with its three timed variants."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_one_rank_nccl_run_reports_the_three_sharded_forms():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sharded", "--workload",
+           "resnet50_fedadam_k64", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1
+    for form in ("no_collective", "allgather", "allgather_pipelined"):
+        assert out[form]["value"] > 0 and out[form]["ms_per_step"] > 0
+    assert out["value"] == out["allgather_pipelined"]["value"]
+    assert out["config"]["params_total"] == 25557032                # parameters, without BN statistics
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1
+    assert rf["algorithmic_bytes_per_launch"] == 4 * (64 + 6) * out["config"]["params_per_gpu"]
+
+
+def test_one_gpu_line_lists_every_benchmark_configuration():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-big", "--no-end-to-end"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["config"]["workload"] == "resnet18_fedavg_k100" and out["scaling"] == "weak"
+    names = [w["workload"] for w in out["workloads"]]
+    assert names == ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "flat162m_fedavg_k32",
+                     "vitb16_fedasync", "vitb16_fedbuff_k16"]
+    for w in out["workloads"]:
+        assert 0 < w["frac"] < 1
+        assert abs(w["frac"] - w["algorithmic_bytes_per_launch"] / (w["kernel_avg_ms"] * 1e-3) / 8e12) < 2e-3
+    assert out["north_star_target"]["workload"] == "resnet50_fedadam_k64"
+    assert out["north_star_target"]["frac"] == out["workloads"][0]["frac"]
+    assert out["roofline"]["traffic"] is None or out["roofline"]["traffic_source"]

@@ -1,5 +1,5 @@
-"""World-size-2 rehearsal of the parameter-sharded aggregator on CPU (gloo): the sharding,
-padding and collective logic, with the C oracle standing in for the HIP kernels."""
+"""Multi-rank rehearsals of the parameter-sharded aggregators on CPU (gloo, world size 2 and 3):
+the block map, padding and collective logic, with the C oracle standing in for the HIP kernels."""
 
 import os
 import socket
@@ -39,42 +39,42 @@ def _single_process_reference():
     return g
 
 
-def _worker(rank, world, port, mode, out):
+def _worker(rank, world, port, mode, pieces, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import cpu_backend
-        from appfl_amd.sharded import ShardedFlatAggregator, shard_bounds
-        agg = ShardedFlatAggregator(N, "adam", device="cpu", backend=cpu_backend, **HP)
+        from appfl_amd.sharded import ShardedFlatAggregator
+        agg = ShardedFlatAggregator(N, "adam", device="cpu", backend=cpu_backend, pieces=pieces, **HP)
         base, _, _ = _inputs(0)
         agg.load_global(torch.from_numpy(base))
-        lo, hi = shard_bounds(N, world, rank)
-        assert (lo, hi) == (agg.lo, agg.hi)
+        smap = agg.map
+        assert smap.pieces == pieces and smap.L % 4 == 0 and smap.P >= N
         for r in range(ROUNDS):
             _, xs, w = _inputs(r)
             if mode == "sliced":
-                agg.round_sliced([torch.from_numpy(x[lo:hi].copy()) for x in xs], w)
+                agg.round_sliced([smap.take(torch.from_numpy(x)) for x in xs], w)
             elif mode == "pipelined":
-                # slices padded to the shard length like rows of the staging slab
-                rows = [torch.from_numpy(np.concatenate([x[lo:hi], np.zeros(agg.L - (hi - lo), np.float32)]))
-                        for x in xs]
-                full = agg.round_sliced_gather(rows, w, pieces=3)
+                full = agg.round_sliced_gather([smap.take(torch.from_numpy(x)) for x in xs], w)
                 assert torch.equal(full, agg.all_gather_global())
             else:
                 mine = [k for k in range(K) if k % world == rank]
                 agg.round_whole([torch.from_numpy(xs[k]) for k in mine], [w[k] for k in mine])
+                assert torch.equal(agg.g_full, agg.all_gather_global())
         full = agg.all_gather_global()
+        assert not full[N:].any()                   # the padding of the gathered vector stays zero
         if rank == 0:
             np.save(out, full.numpy()[:N])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("sliced", 2), ("pipelined", 2), ("whole", 2),
-                                        ("pipelined", 3), ("whole", 3)])
-def test_multi_rank_sharded_adam(mode, world, tmp_path):
+@pytest.mark.parametrize("mode,world,pieces", [("sliced", 2, 1), ("pipelined", 2, 3), ("whole", 2, 2),
+                                               ("pipelined", 3, 4), ("whole", 3, 1),
+                                               ("sliced", 3, 5)])
+def test_multi_rank_sharded_adam(mode, world, pieces, tmp_path):
     out = str(tmp_path / "g.npy")
-    mp.spawn(_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, pieces, out), nprocs=world, join=True)
     got, want = np.load(out), _single_process_reference()
     if mode in ("sliced", "pipelined"):
         # every element sees the same operations in the same order as on one GPU
@@ -84,16 +84,36 @@ def test_multi_rank_sharded_adam(mode, world, tmp_path):
         assert np.max(np.abs(got - want)) <= 1e-6 * np.max(np.abs(want))
 
 
-def test_shard_bounds_cover_the_vector():
-    from appfl_amd.sharded import shard_bounds, shard_length
-    for n in (1, 3, 4, 5, 1023, 10007, 25557032):
-        for world in (1, 2, 4, 8):
-            L = shard_length(n, world)
-            assert L % 4 == 0 and L * world >= n
-            spans = [shard_bounds(n, world, r) for r in range(world)]
-            assert spans[0][0] == 0 and spans[-1][1] == n
-            for (a, b), (c, d) in zip(spans, spans[1:]):
-                assert b == c and a <= b and c <= d
+def test_shard_map_covers_the_vector_exactly_once():
+    from appfl_amd.sharded import ShardMap, default_pieces
+    for n in (0, 1, 3, 4, 5, 1023, 10007, 25557032):
+        for world in (1, 2, 3, 8):
+            for pieces in (1, 2, 4, 7):
+                maps = [ShardMap(n, world, r, pieces) for r in range(world)]
+                m0 = maps[0]
+                assert m0.per % 4 == 0 and m0.L == pieces * m0.per and m0.P == world * m0.L >= n
+                spans = sorted((lo, hi) for m in maps for lo, hi, _ in m.windows())
+                pos = 0
+                for lo, hi in spans:
+                    assert lo == pos and hi > lo
+                    pos = hi
+                assert pos == n
+                for m in maps:
+                    # live elements are a prefix of the local storage
+                    loc = 0
+                    for lo, hi, off in m.windows():
+                        assert off == loc or (off % m.per == 0 and loc % m.per == 0 and off == loc)
+                        loc = off + hi - lo
+                        if hi - lo < m.per:
+                            break
+                    assert m.n_local == sum(hi - lo for lo, hi, _ in m.windows())
+                    # block (p, r) sits where the in-place gather of row p puts it
+                    for p in range(pieces):
+                        a, b = m.row(p)
+                        assert (a + m.rank * m.per, min(n, a + (m.rank + 1) * m.per))[0] == \
+                            (p * world + m.rank) * m.per
+    assert default_pieces(1_300_000_000, 8) == 4 and default_pieces(25_557_032, 8) == 1
+    assert default_pieces(1_300_000_000, 2) == 8
 
 
 def _sd_worker(rank, world, port, out):
@@ -105,16 +125,33 @@ def _sd_worker(rank, world, port, out):
         from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
         cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size")
         agg = ShardedFedAvgAggregator(S.ToyModel(), cfg, None, algorithm="FedAdam", device="cpu",
-                                      backend=cpu_backend)
+                                      backend=cpu_backend, pieces=3)
         for c in range(5):
             agg.set_client_sample_size(c, 4 + 3 * c)
         recs = []
+        if rank == 0:
+            # before the first round only the serving rank answers a client: must not hang
+            recs.append({k: v.numpy().copy() for k, v in agg.get_parameters().items()})
         for r, K in enumerate([2, 5, 3]):
             local = {c: S.make_state(S.TOY, seed=700 + 10 * r + c) for c in range(K)}
             if r == 1:
                 del local[2]["fc.weight"]            # a client lacking a weighted entry
-            recs.append({k: v.numpy().copy() for k, v in agg.aggregate(local).items()})
-        if rank == 1:                                   # every rank holds the whole result
+            if r == 2:
+                for c, m in local.items():          # staged on arrival, as a scheduler would
+                    agg.stage(c, m)
+            out_r = agg.aggregate(local)
+            if rank == 0:
+                recs.append({k: v.numpy().copy() for k, v in out_r.items()})
+                # between rounds ONLY rank 0 serves get_parameters: local, no collective
+                again = agg.get_parameters()
+                for k in out_r:
+                    assert again[k].numpy().tobytes() == out_r[k].numpy().tobytes(), k
+            elif rank == 1 and r == 2:
+                chunk, meta = None, None
+                agg.set_model_chunk_size(600)
+                chunk, meta = agg.get_parameters(_request_chunked=True)
+                assert meta["_total_chunks"] == 2 and list(chunk) == meta["_chunk_keys"]
+        if rank == 0:
             np.save(out, np.array(recs, dtype=object), allow_pickle=True)
     finally:
         dist.destroy_process_group()
@@ -130,15 +167,19 @@ def test_two_rank_state_dict_aggregator_matches_single_process_oracle(tmp_path):
     ora = OA.OracleFedAdam(S.ToyModel(), cfg, None)
     for c in range(5):
         ora.set_client_sample_size(c, 4 + 3 * c)
+    wants = [ora.get_parameters()]
     for r, K in enumerate([2, 5, 3]):
         local = {c: S.make_state(S.TOY, seed=700 + 10 * r + c) for c in range(K)}
         if r == 1:
             del local[2]["fc.weight"]
-        want = ora.aggregate(local)
-        assert list(got[r]) == list(want)
+        wants.append(ora.aggregate(local))
+    assert len(got) == len(wants)
+    for i, want in enumerate(wants):
+        assert list(got[i]) == list(want)
         for k in want:
-            assert got[r][k].dtype == want[k].dtype and got[r][k].shape == want[k].shape, k
-            assert got[r][k].tobytes() == want[k].tobytes(), (r, k)
+            w = want[k].numpy() if isinstance(want[k], torch.Tensor) else want[k]
+            assert got[i][k].dtype == w.dtype and got[i][k].shape == w.shape, k
+            assert got[i][k].tobytes() == w.tobytes(), (i, k)
 
 
 TINY = {"w": ((5,), "f32"), "n": ((), "i64")}
@@ -157,14 +198,14 @@ def _tiny_worker(rank, world, port, out):
         for r in range(2):
             local = {c: S.make_state(TINY, seed=40 * r + c) for c in range(3)}
             recs.append({k: v.numpy().copy() for k, v in agg.aggregate(local).items()})
-        assert agg._flat.hi - agg._flat.lo == (4, 1, 0)[rank]
-        if rank == 2:                                   # the rank whose slice is empty
+        assert agg._map.n_local == (4, 1, 0)[rank]
+        if rank == 2:                                   # the rank whose blocks are all empty
             np.save(out, np.array(recs, dtype=object), allow_pickle=True)
     finally:
         dist.destroy_process_group()
 
 
-def test_three_ranks_on_a_five_element_model_one_slice_empty(tmp_path):
+def test_three_ranks_on_a_five_element_model_one_rank_empty(tmp_path):
     import scenarios as S
     from oracle import aggregators as OA
     out = str(tmp_path / "recs.npy")
