@@ -46,6 +46,10 @@ struct ReduceArgs {
     int apply;  // 1: write g (0 = step-only mode)
     int wt;     // 1: results leave with write-through (sc0 sc1) stores
     int il;     // persistent kernel: 1 = tiles dealt round-robin to the blocks, 0 = contiguous ranges
+    int sync;   // persistent kernel, chip-wide write phases: bit 1 = the blocks meet before their
+                // result bursts, bit 0 = and again after the bursts have drained; 0 = no phases
+    int phase_tiles;       // persistent kernel: tiles per phase (one burst); 0 = all the chip can park
+    unsigned* sync_word;   // zeroed counter the blocks of this launch meet on (sync != 0)
     Hyper h;
 };
 
@@ -289,17 +293,38 @@ __global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
 // Persistent variant: one 256-thread block per CU takes every gridDim.x-th 16-KiB tile of the
 // parameter axis (so at any moment the chip works on one contiguous stretch of every client row
 // -- measured 1.5-2 % faster than giving each block a contiguous range of its own) and parks each
-// tile's results in LDS (every thread only ever touches its own slots, so no barrier is needed);
-// after kStashBytes of results it writes them out in one burst of write-through stores.  HBM
-// handles a few large write bursts far better than a 16-KB write trickling out of every tile
-// between the reads (measured on MI355X: the g write-back of a K = 64 round costs 16 % of the
-// kernel when it trickles, 6 % in bursts).
+// tile's results on chip: the first tiles of a phase in LDS (every thread only ever touches its
+// own slots, so no barrier is needed), further ones in registers the pipeline leaves unused.  At
+// the end of a phase it writes them out in one burst of write-through stores.
+//
+// Why: what a result byte costs on MI355X depends on how DILUTED the writes are among the reads.
+// Measured with read-only and write-only kernels alternating over chunks of the vector (K = 32,
+// 650 MB rows): 3.25 ms with 35 MB written per phase, 3.45 ms with 17 MB, 3.9 ms with 8 MB or
+// less -- against 3.06 ms for the reads alone; and the same 102 MB of results cost 0.045 ms
+// extra when spread over an 8-client round but 0.15 ms over a 128-client round.  So the blocks
+// write in PHASES: all of them MEET (grid_meet, a bounded wait that carries no data) before
+// their bursts, each drains its own burst (s_waitcnt vmcnt(0) on write-through stores), and only
+// then issues the loads of the next phase, whose pipeline therefore starts empty.  Worth
+// 2.5-3.5 % on a 650 MB vector over bursts that every block fires on its own; meeting again
+// after the bursts, meeting between bursts, or dealing the tiles in groups so that a burst is
+// contiguous, is not.  A vector that the chip can park whole (up to 18 tiles per CU under plain
+// FedAvg) is written in one burst when all its reads are done (+1-2 % over several bursts).
 
 constexpr int kStashVpt = 4;
 constexpr int kStashUnroll = 8;
 constexpr unsigned kStashTile = kThreads * kStashVpt;                 // vectors per tile
 constexpr unsigned kStashVecBytes = kStashTile * 16;                  // 16 KiB per result vector
-constexpr unsigned kStashBytes = 144 * 1024;                          // LDS budget of a block
+constexpr unsigned kStashBytes = 160 * 1024;                          // LDS budget of a block
+
+#ifndef FA_STASH_MAX_TILES
+#define FA_STASH_MAX_TILES 10
+#endif
+constexpr int kStashMaxTiles = FA_STASH_MAX_TILES;
+#ifndef FA_STASH_REG_BUDGET
+#define FA_STASH_REG_BUDGET 128
+#endif
+constexpr unsigned kPhaseTiles = 8;   // tiles per phase of a vector too long to be parked whole
+constexpr int kStashRegBudget = FA_STASH_REG_BUDGET;   // registers per lane that may hold parked results
 
 // What a launch writes back per tile.
 enum { kOutFinal = 0, kOutFinalStep = 1, kOutStepOnly = 2 };
@@ -311,13 +336,57 @@ struct StashShape {
             ? 1
             : 1 + (OPT != FA_OPT_NONE) + (OPT >= FA_OPT_ADAM) + (MODE == kOutFinalStep);
     static constexpr int kTiles =
-        (kStashBytes / kStashVecBytes / kVectors) > 8 ? 8 : (kStashBytes / kStashVecBytes / kVectors);
+        (kStashBytes / kStashVecBytes / kVectors) > kStashMaxTiles ? kStashMaxTiles : (kStashBytes / kStashVecBytes / kVectors);
+    // further tiles of a phase whose results wait in registers (16 per result vector and tile):
+    // at one wave per SIMD the pipeline leaves about a quarter of the 512 registers unused
+    static constexpr int kRegTiles =
+        (OPT == FA_OPT_NONE ? kStashRegBudget : OPT == FA_OPT_AVGM ? kStashRegBudget / 2 : 0) / (16 * kVectors);
 };
 
 __device__ __forceinline__ void burst_store(float* base, unsigned bytes, unsigned idx, const f4& v) {
     // write-through (sc0 sc1) 128-bit store
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, static_cast<int>(bytes), 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rs, idx * 16u, 0, 17);
+}
+
+// Meeting point of all blocks of a persistent launch.  It carries no data (nothing one block
+// writes is read by another), so it needs no fences: its only purpose is TIMING -- the blocks'
+// result bursts should hit HBM together, with nobody reading meanwhile (see the kernel below).
+// The wait is bounded: a block that never shows up (not resident because something else holds
+// its CU) costs the others a time-out once, after which they stop waiting; results never
+// depend on it.
+constexpr unsigned kSyncPolls = 96;
+
+struct GridMeet {
+    unsigned* word;
+    unsigned arrivals;   // meetings this block has attended
+    bool gave_up;
+};
+
+__device__ __forceinline__ void grid_meet(GridMeet& m) {
+    ++m.arrivals;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(m.word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!m.gave_up) {
+            const unsigned target = m.arrivals * gridDim.x;
+            unsigned polls = 0;
+            while (__hip_atomic_load(m.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++polls >= kSyncPolls) {
+                    m.gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// A block that leaves before the others still counts for the meetings it skips.
+__device__ __forceinline__ void grid_meet_leave(GridMeet& m, unsigned expected) {
+    if (threadIdx.x == 0 && expected > m.arrivals)
+        __hip_atomic_fetch_add(m.word, expected - m.arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The client loop of the persistent kernel is software-pipelined ACROSS tiles: two register
@@ -330,7 +399,9 @@ __device__ __forceinline__ void burst_store(float* base, unsigned bytes, unsigne
 template <int OPT, int MODE>
 __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceArgs a) {
     constexpr int NV = StashShape<OPT, MODE>::kVectors;
-    constexpr int S = StashShape<OPT, MODE>::kTiles;
+    constexpr int S = StashShape<OPT, MODE>::kTiles;       // tiles of a phase parked in LDS
+    constexpr int RT = StashShape<OPT, MODE>::kRegTiles;   // ... and in registers
+    constexpr int PT = S + RT;                             // tiles per phase (one burst)
     constexpr int U = kStashUnroll, VPT = kStashVpt;
     constexpr bool kHasV = MODE != kOutStepOnly && OPT != FA_OPT_NONE;
     constexpr bool kHasM = MODE != kOutStepOnly && OPT >= FA_OPT_ADAM;
@@ -342,6 +413,11 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
     unsigned r0 = u0 * 64u;
     unsigned r1 = (u1 * 64u < a.n) ? u1 * 64u : a.n;
     unsigned ntiles, tstride = kStashTile, tlen = kStashTile;
+    // Chip-wide write phases (only with round-robin tiles, where all blocks have equal work).
+    bool phased = a.sync != 0 && a.il != 0 && a.sync_word != nullptr;
+    unsigned P = static_cast<unsigned>(PT);   // tiles per phase: at most what LDS and the spare registers hold
+    GridMeet meet = {a.sync_word, 0u, false};
+    unsigned meetings = 0;
     if (a.il) {
         // Every block gets the same number of equally long tiles where that is possible: the
         // tile is shortened, in steps of one wave-row (64 vectors = 1 KiB; finer steps cost
@@ -357,7 +433,23 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         // eighth one: a consistent +0.5 % (fewer rows open per XCD's slice of the fabric).
         unsigned slot = blockIdx.x;
         if (gridDim.x % 8 == 0) slot = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
-        if (slot >= total) return;
+        // every block attends as many meetings as the busiest block
+        const unsigned most = (total + gridDim.x - 1) / gridDim.x;
+        // A vector short enough to be parked whole is written in one burst at the very end, with
+        // no meeting; a longer one in phases of kPhaseTiles tiles (measured on a 155-tile-per-CU
+        // vector: phases of 4..8 tiles 3.5 % faster than none, of 10..18 tiles 1-2.5 %: the
+        // blocks drift apart within a long phase and then wait for each other at its end).
+        if (a.phase_tiles > 0) {
+            if (static_cast<unsigned>(a.phase_tiles) < P) P = static_cast<unsigned>(a.phase_tiles);
+        } else if (most > P && P > kPhaseTiles) {
+            P = kPhaseTiles;
+        }
+        if (most <= P) phased = false;
+        if (phased) meetings = ((most + P - 1) / P) * (((a.sync & 1) ? 1u : 0u) + ((a.sync & 2) ? 1u : 0u));
+        if (slot >= total) {
+            grid_meet_leave(meet, meetings);
+            return;
+        }
         ntiles = (total - slot + gridDim.x - 1) / gridDim.x;
         r0 = slot * tlen;
         r1 = a.n;
@@ -383,16 +475,24 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
     Pack<4> xa[U][VPT], xb[U][VPT];
     Pack<4> g_cur[VPT], s_cur[VPT], m_cur[VPT], v_cur[VPT];
     Pack<4> g_nxt[VPT], s_nxt[VPT], m_nxt[VPT], v_nxt[VPT];
+    f4 rpark[RT > 0 ? RT : 1][NV][VPT];   // results of tiles S.. of the phase (static indices only)
     unsigned it = 0, ct = 0;   // tile being issued / consumed
     int ib = 0, cb = 0;        // client set within that tile
+    // Phased mode: loads are only issued for the tiles of the current phase (S tiles = one
+    // burst), so that the pipeline is empty when the burst goes out; `full_*` tell which
+    // register set holds an issued, not yet consumed client set.
+    unsigned issue_end = phased ? P : 0xFFFFFFFFu;
+    bool full_a = false, full_b = false, burst_done = false;
 
+    auto tile_start = [&](unsigned tile) -> unsigned { return r0 + tile * tstride; };
     auto vec_index = [&](unsigned tile, int p) -> unsigned {
         const unsigned off = p * kThreads + threadIdx.x;
         const unsigned i = r0 + tile * tstride + off;
         return (off < tlen && i < r1) ? i : r1 - 1;   // idle lanes redo the last vector, never store
     };
-    auto issue = [&](Pack<4> (&x)[U][VPT]) {
-        if (it >= ntiles) return;
+    auto issue = [&](Pack<4> (&x)[U][VPT], bool& full) {
+        if (it >= ntiles || it >= issue_end) return;
+        full = true;
         unsigned idx[VPT];
 #pragma unroll
         for (int p = 0; p < VPT; ++p) idx[p] = vec_index(it, p);
@@ -419,7 +519,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         }
     };
     auto finish_tile = [&]() {
-        const int j = static_cast<int>(ct % S);
+        const int j = static_cast<int>(ct % P);
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
             if (a.last && MODE != kOutStepOnly) {
@@ -437,7 +537,15 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
             auto park = [&](const Pack<4>& v) {
                 f4 t;
                 t.x = v.e[0]; t.y = v.e[1]; t.z = v.e[2]; t.w = v.e[3];
-                stash[j][c++][p][threadIdx.x] = t;
+                if (j < S) {
+                    stash[j][c][p][threadIdx.x] = t;
+                } else {
+                    // j is the same for the whole block: one of these runs, the index is static
+#pragma unroll
+                    for (int q = 0; q < RT; ++q)
+                        if (j - S == q) rpark[q][c][p] = t;
+                }
+                ++c;
             };
             if (MODE == kOutStepOnly) {
                 park(s_cur[p]);
@@ -448,23 +556,39 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
                 if (MODE == kOutFinalStep) park(s_cur[p]);
             }
         }
-        if (j == S - 1 || ct + 1 == ntiles) {
+        if (j == static_cast<int>(P) - 1 || ct + 1 == ntiles) {
             const unsigned first = ct - static_cast<unsigned>(j);
+            burst_done = true;
+            if (phased && (a.sync & 2)) grid_meet(meet);   // nobody writes before everybody has read
 #pragma unroll 1
-            for (int jj = 0; jj <= j; ++jj) {
+            for (int jj = 0; jj <= j && jj < S; ++jj) {
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
 #pragma unroll
                     for (int p = 0; p < VPT; ++p) {
                         const unsigned off = p * kThreads + threadIdx.x;
-                        const unsigned i = r0 + (first + jj) * tstride + off;
+                        const unsigned i = tile_start(first + jj) + off;
                         if (off < tlen && i < r1) burst_store(dst[c], nbytes, i, stash[jj][c][p][threadIdx.x]);
                     }
             }
+#pragma unroll
+            for (int q = 0; q < RT; ++q) {
+                if (S + q <= j) {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+#pragma unroll
+                        for (int p = 0; p < VPT; ++p) {
+                            const unsigned off = p * kThreads + threadIdx.x;
+                            const unsigned i = tile_start(first + S + q) + off;
+                            if (off < tlen && i < r1) burst_store(dst[c], nbytes, i, rpark[q][c][p]);
+                        }
+                }
+            }
         }
     };
-    auto consume = [&](Pack<4> (&x)[U][VPT]) {
-        if (ct >= ntiles) return;
+    auto consume = [&](Pack<4> (&x)[U][VPT], bool& full) {
+        if (!full) return;
+        full = false;
         if (cb == 0) {
 #pragma unroll
             for (int p = 0; p < VPT; ++p) {
@@ -502,14 +626,28 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         }
     };
 
-    issue(xa);
-    issue(xb);
+    // After a burst in phased mode: wait until this block's stores have left (they are
+    // write-through, so their completion means the bytes are on their way to HBM), meet the
+    // other blocks, then open the next phase's tiles for issue.
+    auto end_phase = [&]() {
+        if (!burst_done) return;
+        burst_done = false;
+        if (!phased) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pipeline is empty, only stores are out
+        if (a.sync & 1) grid_meet(meet);
+        issue_end += P;
+    };
+    issue(xa, full_a);
+    issue(xb, full_b);
     while (ct < ntiles) {
-        consume(xa);
-        issue(xa);
-        consume(xb);
-        issue(xb);
+        consume(xa, full_a);
+        end_phase();
+        issue(xa, full_a);
+        consume(xb, full_b);
+        end_phase();
+        issue(xb, full_b);
     }
+    if (phased) grid_meet_leave(meet, meetings);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -857,6 +995,10 @@ Shape g_shape = {0, 8, 1, kMaxBlocks, 2};
 constexpr unsigned kLeanTileVectors = 1u << 20;   // 16 MiB of g
 int g_write_through = 1;   // fa_tune's nt field: bit 1 set = plain result stores
 int g_interleave = 1;      // fa_tune's nt field: bit 2 set = contiguous per-block ranges in the persistent kernel
+int g_phase_tiles = 0;     // fa_tune's nt field, bits 8-12: tiles per phase of the persistent kernel (0: chosen per launch)
+int g_sync = 2;            // fa_tune's nt field: chip-wide write phases of the persistent kernel -- default: the
+                           // blocks meet before their bursts; bit 4 set = no phases; bit 5 set = they also
+                           // meet after the bursts have drained
 
 // From this many clients on, the tile-per-block kernel on a long vector takes two vectors per
 // thread instead of one.
@@ -875,8 +1017,49 @@ int device_cu_count() {
     return cus[dev];
 }
 
+}  // namespace
+
+// Meeting counters of the persistent kernel's launches: kSyncSlots slots of one 256-byte line
+// each, handed out round-robin and zeroed on the launch's stream just before the launch.  (The
+// name is a host-side handle; the per-device address comes from hipGetSymbolAddress.)
+static __device__ __align__(256) unsigned sync_words[64 * 64];
+
+namespace {
+
+constexpr int kSyncSlots = 64;
+constexpr int kMaxDevices = 64;
+std::mutex g_symbol_mutex;
+unsigned* g_sync_ptr[kMaxDevices] = {nullptr};
+unsigned g_sync_next[kMaxDevices] = {0};
+
+// A zeroed meeting counter for one launch on the current device (NULL: run without meetings).
+unsigned* next_sync_word(hipStream_t st) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    unsigned* word = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(g_symbol_mutex);
+        if (!g_sync_ptr[dev]) {
+            unsigned* p = nullptr;
+            if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(sync_words)) != hipSuccess || !p) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            g_sync_ptr[dev] = p;
+        }
+        word = g_sync_ptr[dev] + 64 * (g_sync_next[dev]++ % kSyncSlots);
+    }
+    if (hipMemsetAsync(word, 0, 256, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return word;
+}
+
 template <int OPT, int MODE>
-int launch_stash_m(const ReduceArgs& a, hipStream_t st) {
+int launch_stash_m(const ReduceArgs& a0, hipStream_t st) {
+    ReduceArgs a = a0;
+    a.sync_word = (a.sync && a.il) ? next_sync_word(st) : nullptr;
     hipLaunchKernelGGL((reduce_stash_kernel<OPT, MODE>), dim3(device_cu_count()), dim3(kThreads), 0, st, a);
     return launch_status();
 }
@@ -1004,6 +1187,8 @@ int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStrea
         a.h = c.h;
         a.wt = g_write_through;
         a.il = g_interleave;
+        a.sync = g_sync;
+        a.phase_tiles = g_phase_tiles;
         a.n = static_cast<unsigned>(vec ? len / 4 : len);
         int rc = vec ? launch_reduce<4>(c.opt, a, st) : launch_reduce<1>(c.opt, a, st);
         if (rc != FA_OK) return rc;
@@ -1194,8 +1379,6 @@ static __device__ __align__(256) float scratch[FA_STATIC_WS_FLOATS];
 
 namespace {
 
-constexpr int kMaxDevices = 64;
-std::mutex g_scratch_mutex;
 float* g_scratch_ptr[kMaxDevices] = {nullptr};
 
 // Address of the current device's copy of `scratch` (looked up on the first call per device).
@@ -1204,7 +1387,7 @@ int scratch_for_current_device(float** out) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_code(e);
     if (dev < 0 || dev >= kMaxDevices) return FA_ERR_INVALID;
-    std::lock_guard<std::mutex> hold(g_scratch_mutex);
+    std::lock_guard<std::mutex> hold(g_symbol_mutex);
     if (!g_scratch_ptr[dev]) {
         float* p = nullptr;
         e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
@@ -1241,6 +1424,8 @@ int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash) {
     g_shape.nt = (nt & 1) ? 1 : 0;
     g_write_through = (nt & 2) ? 0 : 1;
     g_interleave = (nt & 4) ? 0 : 1;
+    g_sync = (nt & 16) ? 0 : ((nt & 32) ? 3 : 2);
+    g_phase_tiles = (nt >> 8) & 31;   // experiment encoding: bits 4-5 of nt = sync mode as is
     g_shape.max_blocks = max_blocks > 0 ? max_blocks : kMaxBlocks;
     g_shape.stash = stash;
     return FA_OK;

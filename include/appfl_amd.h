@@ -66,7 +66,9 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * reduce kernels -- vectors per thread (1|2|4; 0 = chosen per call, the default), clients
  * loaded ahead (4|8|16; ignored when vectors per thread is 0), nt (bit 0:
  * non-temporal client loads, bit 1: plain instead of write-through result stores, bit 2: the
- * persistent kernel gives each block one contiguous range instead of every gridDim-th tile),
+ * persistent kernel gives each block one contiguous range instead of every gridDim-th tile,
+ * bit 4: the persistent kernel's blocks do not meet before their result bursts, bit 5: they
+ * also meet after the bursts),
  * grid cap (<= 0: default) of the tile-per-block kernel, and from how many 16-KiB tiles per CU
  * on a launch with a long client list (FedAvg >= 32, FedAvgM >= 48 clients) takes the persistent
  * kernel that parks results in LDS and writes them in bursts (stash: 0 never, < 0 always for
