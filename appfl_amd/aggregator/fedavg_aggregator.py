@@ -34,7 +34,8 @@ from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_req
 
 
 class _ChunkState:
-    """Global state of one chunk of a streamed aggregation (its own layout, vectors, slab)."""
+    """Working set of one chunk of a streamed aggregation (its own layout, vectors, slab); the
+    values live in the aggregator's global state between calls."""
 
     def __init__(self, layout, flats, slab):
         self.layout, self.flats, self.slab = layout, flats, slab
@@ -92,7 +93,10 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._staged_for = None
         self._prestaged: Dict[Any, tuple] = {}   # client_id -> (row, model) staged on arrival
         self._row_of: list = []                  # slab row of the k-th client of this round
-        self._chunks: Dict[tuple, "_ChunkState"] = {}    # streamed aggregation, one per key set
+        self._chunks: Dict[tuple, "_ChunkState"] = {}    # streamed aggregation: working sets per key set
+        # entries of the global state that streamed rounds created outside the flat layout
+        # (name -> device tensor, in the order the reference's dict would hold them)
+        self._extra_state: Dict[str, torch.Tensor] = {}
         self._dl = HostDownloader()
         self._init_lock()
 
@@ -101,13 +105,10 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
     def global_state(self) -> Optional[Dict[str, torch.Tensor]]:
         """{name: device tensor} views of the flat global state (None before the first round)."""
         if self._layout is None:
-            if not self._chunks:
-                return None
-            merged = {}
-            for st in self._chunks.values():
-                merged.update(st.layout.views(st.flats))
-            return merged
-        return self._layout.views(self._flats)
+            return dict(self._extra_state) if self._extra_state else None
+        out = self._layout.views(self._flats)
+        out.update(self._extra_state)
+        return out
 
     def _moment_views(self, flat) -> Dict[str, torch.Tensor]:
         if flat is None:
@@ -133,16 +134,18 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             request_chunked = kwargs.get("_request_chunked", False)
             requested_chunk_id = kwargs.get("_chunk_id", None)
             if self.model_chunk_size is not None and (request_chunked or requested_chunk_id is not None):
-                if self._layout is None:
+                if self._layout is None and not self._extra_state:
                     if self.model is None:
                         raise ValueError("Model is not provided to the aggregator.")
                     source = self.model.state_dict()
                 else:
                     source = None
-                sizes = ({k: v.numel() * v.element_size() for k, v in source.items()}
-                         if source is not None else
-                         {e.name: e.numel * torch.empty((), dtype=e.dtype).element_size()
-                          for e in self._names_layout().entries})
+                if source is not None:
+                    sizes = {k: v.numel() * v.element_size() for k, v in source.items()}
+                else:
+                    sizes = {e.name: e.numel * torch.empty((), dtype=e.dtype).element_size()
+                             for e in self._names_layout().entries}
+                    sizes.update({k: v.numel() * v.element_size() for k, v in self._extra_state.items()})
                 if sum(sizes.values()) > self.model_chunk_size:
                     chunks = split_names_by_size(sizes, self.model_chunk_size)
                     chunk_idx = requested_chunk_id if requested_chunk_id is not None else 0
@@ -159,11 +162,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     meta = {"_chunk_idx": chunk_idx, "_total_chunks": len(chunks),
                             "_chunk_keys": keys}
                     return (result, meta)
-            if self._layout is None and self._chunks:
-                merged = {}
-                for st in self._chunks.values():
-                    merged.update(_download_flats(st.layout, st.flats, self._dl))
-                return merged
+            if self._layout is None and self._extra_state:
+                return self._download()
             if self._layout is None:
                 if self.model is None:
                     raise ValueError("Model is not provided to the aggregator.")
@@ -192,12 +192,27 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 self._layout.view(self._flats, n).copy_(t.detach())
         self._slab = ClientSlab(self._layout, self.device)
 
+    def _adopt_streamed_state(self) -> None:
+        """A whole-model round after streamed rounds only: the global state is what the chunks
+        built (fedavg_aggregator.py:228 finds `global_state` set), in their order."""
+        init, self._extra_state = self._extra_state, {}
+        self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
+                              self.named_parameters)
+        self._flats = self._layout.alloc_state(self.device)
+        for n, t in init.items():
+            self._layout.view(self._flats, n).copy_(t)
+        self._slab = ClientSlab(self._layout, self.device)
+
     def _download(self, names=None) -> Dict[str, torch.Tensor]:
         """Fresh CPU copy of the global state: one D2H copy per dtype, entries are views of it."""
         lay = self._layout
         if names is not None:
-            return {n: lay.view(self._flats, n).cpu() for n in names if n in lay.by_name}
-        return _download_flats(lay, self._flats, self._dl)
+            return {n: (lay.view(self._flats, n) if lay is not None and n in lay.by_name
+                        else self._extra_state[n]).cpu()
+                    for n in names if (lay is not None and n in lay.by_name) or n in self._extra_state}
+        out = _download_flats(lay, self._flats, self._dl) if lay is not None else {}
+        out.update({k: v.cpu() for k, v in self._extra_state.items()})
+        return out
 
     def _client_weights(self, local_models) -> list:
         """fedavg_aggregator.py:343-358."""
@@ -365,7 +380,10 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         with self._lock:
             first = next(iter(local_models.values()))
             if self._layout is None:
-                self._init_global_state(first)
+                if self._extra_state:
+                    self._adopt_streamed_state()
+                else:
+                    self._init_global_state(first)
             K = len(local_models)
             self._stage(local_models)
             fused = getattr(type(self).compute_steps, "_appfl_amd_native", False)
@@ -436,26 +454,38 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
 
     # -- streamed aggregation: fedavg_aggregator.py:406-497 ------------------------------------------
     def _aggregate_chunk(self, local_models, **kwargs) -> Dict:
-        """One chunk of a streamed aggregation: only the keys in `_chunk_keys`, each chunk with
-        its own device-resident state started from the first client's tensors (:416-423).  As in
-        the reference every non-integer key takes the plain FedAvg step here -- no
-        named-parameter test (:466-471) and no server optimizer (subclasses do not override
-        this path)."""
+        """One chunk of a streamed aggregation: only the keys in `_chunk_keys`.  A key the global
+        state already holds (from earlier rounds of either kind) continues from its value, a
+        new key starts from the first client's tensor (:416-423).  As in the reference every
+        non-integer key takes the plain FedAvg step here -- no named-parameter test (:466-471)
+        and no server optimizer (subclasses do not override this path)."""
         chunk_keys = list(list(kwargs["_chunk_keys"].values())[0])
         with self._lock:
             first = next(iter(local_models.values()))
-            tag = tuple(chunk_keys)
+            main = self._layout
+
+            def current(key):
+                if main is not None and key in main.by_name:
+                    return main.view(self._flats, key)
+                return self._extra_state.get(key)
+
+            init = {}
+            for k in chunk_keys:
+                cur = current(k)
+                if cur is not None:
+                    init[k] = cur
+                elif k in first:
+                    init[k] = first[k]
+            tag = tuple((k, tuple(t.shape), t.dtype) for k, t in init.items())
             st = self._chunks.get(tag)
             if st is None:
-                init = {k: first[k] for k in chunk_keys if k in first}
                 lay = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()], None)
-                flats = lay.alloc_state(self.device)
-                with torch.no_grad():
-                    for n, t in init.items():
-                        lay.view(flats, n).copy_(t.detach())
-                st = _ChunkState(lay, flats, ClientSlab(lay, self.device))
+                st = _ChunkState(lay, lay.alloc_state(self.device), ClientSlab(lay, self.device))
                 self._chunks[tag] = st
             lay, K = st.layout, len(local_models)
+            with torch.no_grad():
+                for n, t in init.items():
+                    lay.view(st.flats, n).copy_(t.detach())
             st.slab.reserve(K)
             st.slab.begin_round()
             for k, model in enumerate(local_models.values()):
@@ -472,6 +502,14 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 ops.mean(rows(lay.seg_byte[MEAN_I64]), st.flats["i64"], n=lay.count[MEAN_I64])
             if lay.count[MEAN_I32]:
                 ops.mean(rows(lay.seg_byte[MEAN_I32]), st.flats["i32"], n=lay.count[MEAN_I32])
+            # the chunk's new values become part of the global state
+            with torch.no_grad():
+                for n in init:
+                    cur = current(n)
+                    if cur is not None:
+                        cur.copy_(lay.view(st.flats, n))
+                    else:
+                        self._extra_state[n] = lay.view(st.flats, n).clone()
             out = _download_flats(lay, st.flats, self._dl)
             self._sync_model(self.model, out)        # partial update (:447-452)
             return {k: out[k] for k in chunk_keys if k in out}

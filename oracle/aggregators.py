@@ -86,8 +86,43 @@ class OracleFedAvg(OracleBase):
         self.global_state: Optional[Dict[str, np.ndarray]] = None
         self.step: Dict[str, np.ndarray] = {}
 
-    # fedavg_aggregator.py:136-148
+    def set_model_chunk_size(self, chunk_size):
+        # fedavg_aggregator.py:58-65
+        self.model_chunk_size = chunk_size
+
+    # fedavg_aggregator.py:84-148 (chunk rule: misc/memory_utils.py:317-379)
     def get_parameters(self, **kwargs):
+        request_chunked = kwargs.get("_request_chunked", False)
+        chunk_id = kwargs.get("_chunk_id", None)
+        chunk_size = getattr(self, "model_chunk_size", None)
+        if chunk_size is not None and (request_chunked or chunk_id is not None):
+            if self.global_state is None:
+                if self.model_state is None:
+                    raise ValueError("Model is not provided to the aggregator.")
+                source = self.model_state
+            else:
+                source = self.global_state
+            if sum(v.size * v.itemsize for v in source.values()) > chunk_size:
+                chunks, cur, size = [], [], 0
+                for key in sorted(source):
+                    nbytes = source[key].size * source[key].itemsize
+                    if nbytes > chunk_size:
+                        if cur:
+                            chunks.append(cur)
+                            cur, size = [], 0
+                        chunks.append([key])
+                        continue
+                    if size + nbytes > chunk_size and cur:
+                        chunks.append(cur)
+                        cur, size = [], 0
+                    cur.append(key)
+                    size += nbytes
+                if cur:
+                    chunks.append(cur)
+                idx = chunk_id if chunk_id is not None else 0
+                keys = chunks[idx]
+                return ({k: source[k].copy() for k in keys},
+                        {"_chunk_idx": idx, "_total_chunks": len(chunks), "_chunk_keys": keys})
         if self.global_state is None:
             if self.model_state is None:
                 raise ValueError("Model is not provided to the aggregator.")

@@ -68,12 +68,27 @@ def main():
     import scenarios as S
     A = import_reference()
 
+    from appfl.algorithm.scheduler import AsyncScheduler, SyncScheduler
+    from appfl.misc.utils import get_appfl_aggregator
+
     def factory(cls, model, cfg):
         return getattr(A, cls)(model, DictConfig(cfg), None)
 
+    def loader_factory(cls, model, cfg):
+        # the route the server agent takes (agent/server.py:416-428 -> misc/utils.py:132-144)
+        return get_appfl_aggregator(cls, model, DictConfig(cfg), None)
+
+    def schedulers(kind, agg, num_clients=0):
+        if kind == "sync":
+            return SyncScheduler(DictConfig({"num_clients": num_clients, "same_init_model": True}), agg, None)
+        return AsyncScheduler(DictConfig({"num_clients": num_clients}), agg, None)
+
     arrays, index = {}, {}
     for sc in S.all_scenarios():
-        rec = S.run_scenario(factory, sc)
+        if sc["kind"].startswith("sched"):
+            rec = S.run_scenario(loader_factory, sc, schedulers)
+        else:
+            rec = S.run_scenario(factory, sc)
         entries = []
         for i, (label, d) in enumerate(rec):
             entries.append({"label": label, "sha256": record_hash(d), "names": sorted(d)})

@@ -50,8 +50,27 @@ def same_bits(a, b) -> bool:
     return a.dtype == b.dtype and a.shape == b.shape and np.array_equal(_bits(a), _bits(b))
 
 
+# Element-wise companion of the tensor-scale tolerance: every element within ELEM_RTOL of ITS OWN
+# magnitude, plus one unit in the last place of the tensor's largest magnitude (elements that
+# nearly cancel carry the absolute error of their neighbours; measured worst case over all sqrt
+# scenarios: 8.2e-5 relative / 1024 ulp on such an element, 0.11 of this bound).
+ELEM_RTOL = 1e-5
+worst_seen = {"scale_rel": 0.0, "elem_rel": 0.0, "ulp": 0, "bound_frac": 0.0}
+
+
+def ulp_distance(a, b):
+    """Distance in units in the last place between two float32 arrays (finite values)."""
+    ai = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    bi = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
 def _close(got, want, rtol):
-    """|got - want| <= rtol * max|finite want| elementwise; inf / nan patterns must coincide."""
+    """|got - want| <= rtol * max|finite want| for every element AND
+    |got - want| <= ELEM_RTOL * |want| + 2**-23 * max|finite want| element by element;
+    inf / nan patterns must coincide.  Returns (ok, error relative to the tensor's scale)."""
     got, want = np.asarray(got), np.asarray(want)
     if want.dtype.kind != "f":
         return np.array_equal(got, want), 0.0
@@ -62,9 +81,18 @@ def _close(got, want, rtol):
         return False, float("inf")
     if not fin.any():
         return True, 0.0
-    scale = float(np.max(np.abs(want[fin]))) or 1.0
-    err = float(np.max(np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64)))) / scale
-    return err <= rtol, err
+    g, w = got[fin].astype(np.float64), want[fin].astype(np.float64)
+    scale = float(np.max(np.abs(w))) or 1.0
+    diff = np.abs(g - w)
+    err = float(np.max(diff)) / scale
+    frac = float(np.max(diff / (ELEM_RTOL * np.abs(w) + 2.0 ** -23 * scale)))
+    nz = w != 0
+    worst_seen["scale_rel"] = max(worst_seen["scale_rel"], err)
+    worst_seen["bound_frac"] = max(worst_seen["bound_frac"], frac)
+    if nz.any():
+        worst_seen["elem_rel"] = max(worst_seen["elem_rel"], float(np.max(diff[nz] / np.abs(w[nz]))))
+    worst_seen["ulp"] = max(worst_seen["ulp"], int(ulp_distance(got[fin], want[fin]).max()))
+    return err <= rtol and frac <= 1.0, err
 
 
 def check_records(sc_id, rec, rtol=None):
@@ -97,6 +125,7 @@ def check_records(sc_id, rec, rtol=None):
             else:
                 ok, err = _close(mine, g, rtol)
                 worst = max(worst, err)
-                assert ok, f"{sc_id}/{label}/{k}: relative error {err:.3g} > {rtol}"
+                assert ok, (f"{sc_id}/{label}/{k}: error {err:.3g} of the tensor's scale (limit {rtol}) "
+                            f"or an element beyond {ELEM_RTOL} of its own magnitude + 1 ulp of the scale")
         assert rtol is not None, f"{sc_id}/{label}: hash differs (in a tensor stored by hash only)"
     return worst

@@ -204,6 +204,13 @@ def chunked_scenarios() -> List[Dict]:
                     "cfg": dict(HP[cls], client_weights_mode="sample_size"),
                     "rounds": [2, 3], "chunk_bytes": 600,
                     "sample_sizes": {c: 4 + 5 * c for c in range(6)}})
+    # whole-model rounds after streamed ones continue from the state the chunks built, in the
+    # chunks' (name-sorted) order
+    for cls, with_model in (("FedAvgAggregator", False), ("FedAvgMAggregator", True)):
+        out.append({"id": f"{cls[:-10]}-chunked-then-whole-{'model' if with_model else 'nomodel'}",
+                    "kind": "chunked", "cls": cls, "spec": "toy", "model": with_model,
+                    "cfg": dict(HP[cls], client_weights_mode="equal"),
+                    "rounds": [2], "chunk_bytes": 600, "whole_after": [3, 2], "sample_sizes": {}})
     return out
 
 
@@ -272,9 +279,90 @@ def secure_scenarios() -> List[Dict]:
     return out
 
 
+def getparams_scenarios() -> List[Dict]:
+    """Chunked `get_parameters` replies (fedavg_aggregator.py:84-134 with the chunk rule of
+    misc/memory_utils.py:317-379): before and after the first round, with and without a model,
+    first-request form (`_request_chunked`) and per-chunk form (`_chunk_id`), and a chunk size
+    above the model's size (plain reply)."""
+    out = []
+    for cls, with_model, spec in (("FedAvgAggregator", True, "toy"), ("FedAvgAggregator", False, "toy"),
+                                  ("FedAdamAggregator", True, "toy"), ("FedAvgMAggregator", False, "ragged")):
+        out.append({"id": f"{cls[:-10]}-getparams-{'model' if with_model else 'nomodel'}-{spec}",
+                    "kind": "getparams", "cls": cls, "spec": spec, "model": with_model,
+                    "cfg": dict(HP[cls], client_weights_mode="equal"),
+                    "chunk_bytes": [600, 10 ** 9], "rounds": [3, 2], "sample_sizes": {}})
+    return out
+
+
+def sched_scenarios() -> List[Dict]:
+    """The aggregator driven by a scheduler, as the server agent drives it: per-client
+    `schedule` calls with Futures and per-client metadata kwargs (sync_scheduler.py:25-107), the
+    initial-model barrier (base_scheduler.py:38-79), a streamed round through the scheduler's
+    chunk bookkeeping, and arrivals through async_scheduler.py:20-42.  The golden records come
+    from the reference's own schedulers (and its `get_appfl_aggregator` loader)."""
+    out = []
+    for cls, with_model in (("FedAvgAggregator", True), ("FedAvgAggregator", False),
+                            ("FedAdamAggregator", True), ("FedYogiAggregator", False)):
+        out.append({"id": f"{cls[:-10]}-sched-sync-{'model' if with_model else 'nomodel'}",
+                    "kind": "sched_sync", "cls": cls, "spec": "toy", "model": with_model,
+                    "cfg": dict(HP[cls], client_weights_mode="sample_size"), "num_clients": 3,
+                    "rounds": 3, "streamed_round": cls == "FedAvgAggregator", "chunk_bytes": 600,
+                    "sample_sizes": {"c0": 12, "c1": 30, "c2": 7}})
+    for cls, with_model in (("FedAsyncAggregator", True), ("FedAsyncAggregator", False),
+                            ("FedBuffAggregator", False)):
+        cfg = dict(STALENESS["polynomial"], alpha=0.9, num_clients=3)
+        if cls == "FedBuffAggregator":
+            cfg["K"] = 2
+        out.append({"id": f"{cls[:-10]}-sched-async-{'model' if with_model else 'nomodel'}",
+                    "kind": "sched_async", "cls": cls, "spec": "toy", "model": with_model, "cfg": cfg,
+                    "script": ASYNC_SCRIPT[:6], "sample_sizes": {}})
+    return out
+
+
 def all_scenarios() -> List[Dict]:
     return (sync_scenarios() + async_scenarios() + chunked_scenarios() + mix_scenarios()
-            + secure_scenarios())
+            + secure_scenarios() + getparams_scenarios() + sched_scenarios())
+
+
+def _meta_record(meta: Dict) -> Dict[str, np.ndarray]:
+    """A chunk reply's metadata as arrays (so it is hashed and stored like tensors)."""
+    return {"_chunk_idx": np.array(meta["_chunk_idx"], np.int64),
+            "_total_chunks": np.array(meta["_total_chunks"], np.int64),
+            "_chunk_keys": np.frombuffer("\n".join(meta["_chunk_keys"]).encode(), dtype=np.uint8).copy()}
+
+
+def _reply_record(reply) -> Dict[str, np.ndarray]:
+    """get_parameters reply: a state dict, or (chunk dict, metadata)."""
+    if isinstance(reply, tuple):
+        d = _snap(reply[0])
+        assert list(reply[0]) == list(reply[1]["_chunk_keys"])
+        d.update({f"meta.{k}": v for k, v in _meta_record(reply[1]).items()})
+        return d
+    d = _snap(reply)
+    d["meta.plain"] = np.array(1, np.int64)
+    return d
+
+
+def _error_record(e: Exception) -> Dict[str, np.ndarray]:
+    return {"message": np.frombuffer(f"{type(e).__name__}: {e}".encode(), dtype=np.uint8).copy()}
+
+
+def default_schedulers(kind: str, agg, num_clients: int = 0):
+    """The package's own scheduling stand-ins, adapted to `schedule(client_id, model, **kw)`."""
+    from appfl_amd import harness as H
+
+    class _Sched:
+        def __init__(self, h):
+            self.h = h
+            self.get_parameters = h.get_parameters
+            self.get_num_global_epochs = h.get_num_global_epochs
+
+        def schedule(self, client_id, local_model, **kwargs):
+            return self.h.global_update(client_id, local_model, **kwargs)
+
+    if kind == "sync":
+        return _Sched(H.SerialSyncHarness(agg, num_clients))
+    return _Sched(H.SerialAsyncHarness(agg))
 
 
 def _state_snapshots(agg) -> List[Tuple[str, Dict]]:
@@ -286,12 +374,105 @@ def _state_snapshots(agg) -> List[Tuple[str, Dict]]:
     return out
 
 
-def run_scenario(factory: Callable, sc: Dict) -> List[Tuple[str, Dict[str, np.ndarray]]]:
+def _run_getparams(agg, sc, spec) -> List[Tuple[str, Dict]]:
+    rec: List[Tuple[str, Dict]] = []
+
+    def ask(label, **kw):
+        try:
+            rec.append((label, _reply_record(agg.get_parameters(**kw))))
+        except (ValueError, IndexError) as e:
+            rec.append((label + ".error", _error_record(e)))
+
+    def sweep(tag):
+        for cb in sc["chunk_bytes"]:
+            agg.set_model_chunk_size(cb)
+            ask(f"{tag}.cb{cb}.first", _request_chunked=True)
+            for i in range(3):
+                ask(f"{tag}.cb{cb}.chunk{i}", _chunk_id=i)
+            ask(f"{tag}.cb{cb}.plain")
+            ask(f"{tag}.cb{cb}.first_and_id", _request_chunked=True, _chunk_id=1)
+
+    ask("nochunksize.first", _request_chunked=True)      # no chunk size set yet: plain reply
+    sweep("pre")
+    for r, K in enumerate(sc["rounds"]):
+        local = {c: make_state(spec, seed=8000 + 53 * r + c) for c in range(K)}
+        rec.append((f"round{r}", _snap(agg.aggregate(local))))
+        sweep(f"post{r}")
+    return rec
+
+
+def _run_sched_sync(agg, sc, spec, model, schedulers) -> List[Tuple[str, Dict]]:
+    rec: List[Tuple[str, Dict]] = []
+    cids = list(sc["sample_sizes"])
+    sched = schedulers("sync", agg, sc["num_clients"])
+    # initial model: every client asks; the Futures resolve together on the last request
+    futs = []
+    for i, cid in enumerate(cids):
+        try:
+            f = sched.get_parameters(init_model=True)
+            futs.append(f)
+            rec.append((f"init.{cid}", {"done": np.array([int(x.done()) for x in futs], np.int64)}))
+        except ValueError as e:
+            rec.append((f"init.{cid}.error", _error_record(e)))
+    if futs and all(f.done() for f in futs):
+        rec.append(("init.model", _snap(futs[0].result())))
+        rec.append(("init.shared", {"same_object": np.array(int(all(f.result() is futs[0].result()
+                                                                  for f in futs)), np.int64)}))
+    for r in range(sc["rounds"]):
+        states = {cid: make_state(spec, seed=9000 + 41 * r + j) for j, cid in enumerate(cids)}
+        if sc.get("streamed_round") and r == 1:
+            chunks = chunk_keys_by_size(spec, sc["chunk_bytes"])
+            for ci, keys in enumerate(chunks):
+                futs = [sched.schedule(cid, {k: states[cid][k].clone() for k in keys}, _chunk_idx=ci,
+                                       _total_chunks=len(chunks), _chunk_keys=list(keys)) for cid in cids]
+                rec.append((f"round{r}.chunk{ci}", _snap(futs[0].result())))
+                rec.append((f"round{r}.chunk{ci}.epochs",
+                            {"epochs": np.array(sched.get_num_global_epochs(), np.int64)}))
+            continue
+        futs = []
+        for j, cid in enumerate(cids):
+            futs.append(sched.schedule(cid, states[cid], val_accuracy=0.1 * j + r, round=r))
+            rec.append((f"round{r}.{cid}", {"done": np.array([int(x.done()) for x in futs], np.int64),
+                                            "epochs": np.array(sched.get_num_global_epochs(), np.int64)}))
+        rec.append((f"round{r}", _snap(futs[0].result())))
+        rec.append((f"round{r}.shared", {"same_object": np.array(
+            int(all(f.result() is futs[0].result() for f in futs)), np.int64)}))
+        rec.append((f"round{r}.get_parameters", _snap(sched.get_parameters(init_model=False))))
+    return rec
+
+
+def _run_sched_async(agg, sc, spec, schedulers) -> List[Tuple[str, Dict]]:
+    rec: List[Tuple[str, Dict]] = []
+    sched = schedulers("async", agg)
+    for i, (cid, download) in enumerate(sc["script"]):
+        if download:
+            try:
+                rec.append((f"arrival{i}.download",
+                            _snap(sched.get_parameters(init_model=False, client_id=cid))))
+            except ValueError as e:
+                rec.append((f"arrival{i}.download.error", _error_record(e)))
+        st = make_state(spec, seed=9500 + 31 * i + cid)
+        rec.append((f"arrival{i}", _snap(sched.schedule(cid, st, local_steps=5))))
+        rec.append((f"arrival{i}.epochs", {"epochs": np.array(sched.get_num_global_epochs(), np.int64)}))
+    return rec
+
+
+def run_scenario(factory: Callable, sc: Dict, schedulers: Callable = default_schedulers
+                 ) -> List[Tuple[str, Dict[str, np.ndarray]]]:
+    """`schedulers(kind, aggregator, num_clients)` builds the scheduler that drives the
+    aggregator in the scheduler-driven scenarios (default: the package's stand-ins; the golden
+    generator passes the reference's own)."""
     spec = SPECS[sc["spec"]]
     model = ToyModel() if sc["model"] else None
     agg = factory(sc["cls"], model, dict(sc["cfg"]))
     for cid, n in sc["sample_sizes"].items():
         agg.set_client_sample_size(cid, n)
+    if sc["kind"] == "getparams":
+        return _run_getparams(agg, sc, spec)
+    if sc["kind"] == "sched_sync":
+        return _run_sched_sync(agg, sc, spec, model, schedulers)
+    if sc["kind"] == "sched_async":
+        return _run_sched_async(agg, sc, spec, schedulers)
     rec: List[Tuple[str, Dict]] = []
     if model is not None:
         rec.append(("initial", _snap(agg.get_parameters())))
@@ -363,6 +544,9 @@ def run_scenario(factory: Callable, sc: Dict) -> List[Tuple[str, Dict[str, np.nd
                                     _total_chunks={c: len(chunks) for c in cids},
                                     _chunk_keys={c: list(keys) for c in cids})
                 rec.append((f"round{r}.chunk{ci}", _snap(out)))
+        for r, K in enumerate(sc.get("whole_after", [])):
+            local = {c: make_state(spec, seed=3500 + 97 * r + c) for c in range(K)}
+            rec.append((f"whole{r}", _snap(agg.aggregate(local))))
         rec.append(("final_get_parameters", _snap(agg.get_parameters())))
     else:
         gb = sc["cfg"].get("gradient_based", False)

@@ -112,10 +112,18 @@ def test_user_subclass_overriding_compute_steps():
 
 
 def test_chunked_get_parameters():
+    """The chunks of a reply tile the un-chunked reply (the replies themselves are pinned
+    against the reference by the `getparams` golden scenarios) and equal the oracle's chunks."""
     import appfl_amd.aggregator as A
-    agg = A.FedAvgAggregator(None, {}, None)
-    agg.set_model_chunk_size(1024)
-    agg.aggregate({0: S.make_state(S.TOY, seed=1), 1: S.make_state(S.TOY, seed=2)})
+    agg, ora = A.FedAvgAggregator(None, {}, None), OA.OracleFedAvg(None, {}, None)
+    for f in (agg, ora):
+        f.set_model_chunk_size(1024)
+        f.aggregate({0: S.make_state(S.TOY, seed=1), 1: S.make_state(S.TOY, seed=2)})
+    for i in range(ora.get_parameters(_request_chunked=True)[1]["_total_chunks"]):
+        (mine, mmeta), (theirs, tmeta) = agg.get_parameters(_chunk_id=i), ora.get_parameters(_chunk_id=i)
+        assert mmeta == tmeta and list(mine) == list(theirs)
+        for k in theirs:
+            assert golden_util.same_bits(mine[k].numpy(), theirs[k]), (i, k)
     whole = agg.get_parameters()
     first, meta = agg.get_parameters(_request_chunked=True)
     assert meta["_chunk_idx"] == 0 and meta["_total_chunks"] >= 2
@@ -161,12 +169,16 @@ def test_staging_on_arrival_gives_the_same_round():
     import appfl_amd.aggregator as A
     cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size", num_clients=2)
     plain, staged = A.FedAdamAggregator(None, cfg, None), A.FedAdamAggregator(None, cfg, None)
-    for agg in (plain, staged):
+    ora = OA.OracleFedAdam(None, cfg, None)
+    for agg in (plain, staged, ora):
         for c in range(5):
             agg.set_client_sample_size(c, 3 + 2 * c)
     for r, K in enumerate([2, 5, 3]):
         models = {c: S.make_state(S.RAGGED, seed=40 * r + c) for c in range(K)}
         want = plain.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        truth = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        for k in truth:
+            assert golden_util.same_bits(want[k].numpy(), truth[k]), (r, k)
         for c in list(models)[: K - 1]:            # the last client is not pre-staged
             staged.stage(c, models[c])
         if r == 1:
@@ -184,9 +196,11 @@ def test_stage_bytes_reads_the_wire_buffer_in_place():
     import appfl_amd.aggregator as A
     cfg = dict(S.HP["FedYogiAggregator"], client_weights_mode="equal")
     plain, wired = A.FedYogiAggregator(None, cfg, None), A.FedYogiAggregator(None, cfg, None)
+    ora = OA.OracleFedYogi(None, cfg, None)
     for r in range(2):
         models = {c: S.make_state(S.RAGGED, seed=70 * r + c) for c in range(4)}
         want = plain.aggregate(models)
+        truth = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
         views = {}
         for c, m in models.items():
             buf = io.BytesIO()
@@ -196,6 +210,7 @@ def test_stage_bytes_reads_the_wire_buffer_in_place():
         got = wired.aggregate(views)
         for k in want:
             assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (r, k)
+            assert golden_util.same_bits(got[k].numpy(), truth[k]), (r, k)
 
 
 def test_get_parameters_from_other_threads_while_aggregating():

@@ -108,7 +108,7 @@ def test_serial_harness_runs_config1_plumbing_with_the_oracle():
     h.set_sample_size("c0", 100)
     h.set_sample_size("c1", 300)
     with pytest.raises(ValueError):
-        h.get_parameters()
+        h.get_parameters(serial_run=True)
     a, b = S.make_state(spec, seed=1), S.make_state(spec, seed=2)
     f0 = h.global_update("c0", a, blocking=False, val_accuracy=0.1)
     assert not f0.done() and h.get_num_global_epochs() == 0

@@ -32,6 +32,24 @@ def test_first_round_moments_are_bit_exact_even_with_sqrt(cls):
             assert golden_util.record_hash(d) == index[sc["id"]][i]["sha256"], label
 
 
+def test_sqrt_classes_stay_within_the_stated_elementwise_bounds(capsys):
+    """The three aggregators with a sqrt in their step against the reference's vectors: within
+    1e-6 of each tensor's largest magnitude (north_star's tolerance, read per tensor) and,
+    element by element, within 1e-5 of the element's own magnitude plus one ulp of the tensor's
+    scale.  Prints the worst element-wise relative error and ulp distance it saw."""
+    for k in golden_util.worst_seen:
+        golden_util.worst_seen[k] = 0
+    for sc in S.all_scenarios():
+        if S.reference_rtol(sc) is not None:
+            golden_util.check_records(sc["id"], S.run_scenario(oracle_factory, sc), S.reference_rtol(sc))
+    w = golden_util.worst_seen
+    with capsys.disabled():
+        print(f"\nsqrt classes vs reference: worst error {w['scale_rel']:.3g} of the tensor scale, "
+              f"worst element-wise relative error {w['elem_rel']:.3g}, worst distance {w['ulp']} ulp, "
+              f"{w['bound_frac']:.3g} of the element-wise bound")
+    assert w["scale_rel"] <= 1e-6 and w["bound_frac"] <= 1.0 and w["ulp"] <= 4096
+
+
 def test_golden_covers_every_scenario():
     _, index = golden_util.load()
     assert sorted(index) == sorted(s["id"] for s in S.all_scenarios())
@@ -118,3 +136,62 @@ def test_c_oracle_plain_mean(dtype):
     assert np.array_equal(out["w"], g)
     if dtype != np.float32:
         assert list(g[:3]) == [1, 1, -1]
+
+
+class _NaiveAsAggregator:
+    """oracle/torch_naive.py (what bench.py times as cpu_baseline) behind the aggregator
+    interface of the scenarios: client weights as fedavg_aggregator.py:343-358."""
+
+    def __init__(self, cls, cfg):
+        from oracle import torch_naive as TN
+        opt = {"FedAvgAggregator": "none", "FedAvgMAggregator": "avgm", "FedAdamAggregator": "adam",
+               "FedYogiAggregator": "yogi", "FedAdagradAggregator": "adagrad"}[cls]
+        self.naive, self.mode, self.sizes = TN.NaiveFedAvg(opt, cfg), cfg.get("client_weights_mode", "equal"), {}
+
+    def set_client_sample_size(self, cid, n):
+        self.sizes[cid] = n
+
+    def aggregate(self, local_models, **kwargs):
+        total = sum(self.sizes[c] for c in local_models if c in self.sizes)
+        w = {c: (self.sizes[c] / total if self.mode == "sample_size" and c in self.sizes and total > 0
+                 else 1.0 / len(local_models)) for c in local_models}
+        return self.naive.aggregate(local_models, w)
+
+    def get_parameters(self, **kwargs):
+        return {k: v.clone() for k, v in self.naive.global_state.items()}
+
+    @property
+    def m_vector(self):
+        return self.naive.m_vector
+
+    @property
+    def v_vector(self):
+        return self.naive.v_vector
+
+
+@pytest.mark.parametrize("sc", [s for s in S.sync_scenarios() if not s["model"] and not s.get("hash_only")],
+                         ids=lambda s: s["id"])
+def test_torch_naive_cpu_baseline_matches_reference_golden(sc):
+    """The per-tensor torch loops that the benchmark times as `cpu_baseline` reproduce the
+    reference's vectors: bit for bit where no sqrt is involved, within the sqrt tolerance else."""
+    rec = S.run_scenario(lambda cls, model, cfg: _NaiveAsAggregator(cls, cfg), sc)
+    golden_util.check_records(sc["id"], rec, S.reference_rtol(sc))
+
+
+def test_torch_naive_async_mix_matches_the_pinned_oracle():
+    import torch
+    from oracle import torch_naive as TN
+    cfg = dict(S.STALENESS["polynomial"], alpha=0.9, num_clients=3)
+    ora = OA.OracleFedAsync(None, cfg, None)
+    g = None
+    for i, cid in enumerate([0, 1, 0, 2]):
+        st = S.make_state(S.TOY, seed=300 + i)
+        stale = ora.global_step - ora.client_step.get(cid, 0)
+        alpha_t = 0.9 * (stale + 1) ** (-0.5) * (1.0 / 3)
+        want = ora.aggregate(cid, {k: v.clone() for k, v in st.items()})
+        if g is None:
+            g = {k: v.clone() for k, v in st.items()}
+            continue
+        got = TN.naive_async_mix(g, {k: v.clone() for k, v in st.items()}, alpha_t)
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k]), (i, k)
