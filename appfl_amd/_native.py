@@ -53,6 +53,17 @@ SIGNATURES = {
     "fa_buff_flush_mean_i64": (_i, [_p, _p, _i, _sz, _p]),
     "fa_buff_flush_mean_i32": (_i, [_p, _p, _i, _sz, _p]),
     "fa_fill_f32": (_i, [_p, _f, _sz, _p]),
+    "fa_reduce_opt_f64": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),
+    "fa_reduce_step_f64": (_i, [_p, _p, _i, _p, _p, _sz, _p]),
+    "fa_server_opt_step_f64": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _p]),
+    "fa_apply_step_f64": (_i, [_p, _p, _sz, _p]),
+    "fa_mean_f64": (_i, [_p, _i, _p, _sz, _p]),
+    "fa_async_mix_f64": (_i, [_p, _d, _i, _i, _p, _p, _sz, _p]),
+    "fa_buff_accum_f64": (_i, [_p, _d, _i, _p, _p, _i, _sz, _p]),
+    "fa_buff_accum_flush_f64": (_i, [_p, _d, _i, _p, _p, _i, _sz, _p]),
+    "fa_buff_accum_raw_f64": (_i, [_p, _p, _i, _sz, _p]),
+    "fa_buff_flush_mean_f64": (_i, [_p, _p, _i, _sz, _p]),
+    "fa_fill_f64": (_i, [_p, _d, _sz, _p]),
     "fa_synth_fill": (_i, [_p, _p, _sz, _u64, _u64, _f, _p]),
     "fa_pack_host": (_i, [_p, _p, _p, _p, _i, _i]),
     "fa_pack_host_window": (_i, [_p, _p, _p, _p, _i, _sz, _sz, _i]),

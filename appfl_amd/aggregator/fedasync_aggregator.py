@@ -19,25 +19,11 @@ from typing import Any, Dict, Optional, OrderedDict, Union
 import torch
 
 from .. import ops
-from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout
+from ..layout import MEAN_F32, MEAN_F64, MEAN_I32, MEAN_I64, STEP, STEP_F64, Layout
 from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_require,
                               resolve_device)
-
-
-def staleness_fn_factory(staleness_fn_name, **kwargs):
-    """fedasync_aggregator.py:266-277."""
-    if staleness_fn_name == "constant":
-        return lambda u: 1
-    elif staleness_fn_name == "polynomial":
-        a = kwargs["a"]
-        return lambda u: (u + 1) ** (-a)
-    elif staleness_fn_name == "hinge":
-        a = kwargs["a"]
-        b = kwargs["b"]
-        return lambda u: 1 if u <= b else 1.0 / (a * (u - b) + 1.0)
-    else:
-        raise NotImplementedError
+from .staleness import fedasync_staleness
 
 
 class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
@@ -57,8 +43,8 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         else:
             self.named_parameters = None
         kw = cfg_get(self.aggregator_configs, "staleness_fn_kwargs", None) or {}
-        self.staleness_fn = staleness_fn_factory(
-            staleness_fn_name=cfg_get(self.aggregator_configs, "staleness_fn", "constant"), **dict(kw))
+        self.staleness_fn = fedasync_staleness(
+            cfg_get(self.aggregator_configs, "staleness_fn", "constant"), **dict(kw))
         self.alpha = cfg_get(self.aggregator_configs, "alpha", 0.9)
         self.global_step = 0
         self.client_step = {}
@@ -93,7 +79,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
     def _download(self) -> Dict[str, torch.Tensor]:
         lay = self._layout
         host = {}
-        for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
+        for key, n in lay.flat_sizes().items():
             host[key] = self._dl.fetch(self._flats[key], n)
         return lay.views(host)
 
@@ -121,9 +107,8 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
             return
         self._download_warning_issued = True
         self.logger.warning(
-            f"Client {client_id} aggregated with no recorded model download, so staleness is "
-            "measured from its previous upload. Pass `client_id` to `get_parameters` to measure "
-            "staleness from the download instead. (Logged once.)")
+            f"No model download is on record for client {client_id}: its staleness counts from "
+            "its last upload. `get_parameters(client_id=...)` records downloads. (Shown once.)")
 
     _WARN_UNRECORDED = True
 
@@ -155,6 +140,9 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         if lay.count[MEAN_F32]:
             self._flats["f32"][n_step:lay.n_f32].copy_(
                 self._slab.row_view(0, lay.seg_byte[MEAN_F32], lay.count[MEAN_F32], torch.float32))
+        if lay.count[MEAN_F64]:
+            self._flats["f64"][lay.count[STEP_F64]:lay.n_f64].copy_(
+                self._slab.row_view(0, lay.seg_byte[MEAN_F64], lay.count[MEAN_F64], torch.float64))
         if lay.count[MEAN_I64]:
             self._flats["i64"][:lay.count[MEAN_I64]].copy_(
                 self._slab.row_view(0, lay.seg_byte[MEAN_I64], lay.count[MEAN_I64], torch.int64))
@@ -170,6 +158,12 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
                           self._flats["f32"],
                           gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                           sub_form=bool(self.optimize_memory), n=n_step)
+        n64 = self._layout.count[STEP_F64]
+        if n64:
+            ops.async_mix(self._slab.row_view(0, self._layout.seg_byte[STEP_F64], n64, torch.float64),
+                          alpha_t, self._flats["f64"],
+                          gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
+                          sub_form=bool(self.optimize_memory), n=n64)
         self._copy_non_step_entries()
 
     # Arrivals of at least this many weighted elements run as a three-stage pipeline.
@@ -183,7 +177,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         path, so the same bits.  Returns None when it does not apply."""
         lay = self._layout
         n_step = lay.count[STEP]
-        if n_step < self.PIPELINE_MIN_ELEMENTS or any(
+        if n_step < self.PIPELINE_MIN_ELEMENTS or lay.n_f64 or any(
                 not isinstance(t, torch.Tensor) or t.is_cuda for t in local_model.values()):
             return None
         out_f32 = self._dl.lease(torch.float32, lay.n_f32)
@@ -271,8 +265,15 @@ class FedBuffAggregator(FedAsyncAggregator):
                            st["f32"], first,
                            gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                            flush=flush, n=n_step)
+        n64 = lay.count[STEP_F64]
+        if n64:
+            ops.buff_accum(self._slab.row_view(0, lay.seg_byte[STEP_F64], n64, torch.float64), alpha_t,
+                           g["f64"], st["f64"], first,
+                           gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
+                           flush=flush, n=n64)
         # entries outside the step are summed raw and flushed as a mean (:146-152, :84-86)
         for cls, key, dtype, lo in ((MEAN_F32, "f32", torch.float32, n_step),
+                                    (MEAN_F64, "f64", torch.float64, n64),
                                     (MEAN_I64, "i64", torch.int64, 0),
                                     (MEAN_I32, "i32", torch.int32, 0)):
             cnt = lay.count[cls]
@@ -317,7 +318,7 @@ class FedBuffAggregator(FedAsyncAggregator):
         back while the arrival is still being uploaded: the transfers share the full-duplex
         link instead of queueing.  None when no pinned lease is to be had."""
         lay = self._layout
-        if lay.n_f32 < self.PIPELINE_MIN_ELEMENTS:
+        if lay.n_f32 < self.PIPELINE_MIN_ELEMENTS or lay.n_f64:
             return None
         host = {}
         for key, dtype, n in (("f32", torch.float32, lay.n_f32), ("i64", torch.int64, lay.count[MEAN_I64]),

@@ -27,7 +27,8 @@ from typing import Any, Dict, Optional, OrderedDict, Union
 import torch
 
 from .. import ops
-from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout, split_names_by_size
+from ..layout import (MEAN_F32, MEAN_F64, MEAN_I32, MEAN_I64, STEP, STEP_F64, Layout,
+                      split_names_by_size)
 from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_require,
                               resolve_device)
@@ -46,7 +47,7 @@ def _download_flats(lay: Layout, flats: Dict[str, torch.Tensor],
     """Fresh CPU copy of flat state vectors: one D2H copy per dtype, entries are views of it."""
     dl = dl or HostDownloader()
     host = {}
-    for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
+    for key, n in lay.flat_sizes().items():
         host[key] = dl.fetch(flats[key], n)
     return lay.views(host)
 
@@ -87,9 +88,12 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._layout: Optional[Layout] = None
         self._flats: Optional[Dict[str, torch.Tensor]] = None      # global state
         self._slab: Optional[ClientSlab] = None
-        self._m: Optional[torch.Tensor] = None
+        self._m: Optional[torch.Tensor] = None          # moments / step of the fp32 weighted entries
         self._v: Optional[torch.Tensor] = None
         self._step_flat: Optional[torch.Tensor] = None
+        self._m64: Optional[torch.Tensor] = None        # ... and of the float64 ones
+        self._v64: Optional[torch.Tensor] = None
+        self._step_flat64: Optional[torch.Tensor] = None
         self._staged_for = None
         self._prestaged: Dict[Any, tuple] = {}   # client_id -> (row, model) staged on arrival
         self._row_of: list = []                  # slab row of the k-th client of this round
@@ -110,19 +114,20 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         out.update(self._extra_state)
         return out
 
-    def _moment_views(self, flat) -> Dict[str, torch.Tensor]:
-        if flat is None:
+    def _moment_views(self, flat, flat64=None) -> Dict[str, torch.Tensor]:
+        if flat is None and flat64 is None:
             return {}
-        return {e.name: flat[e.offset:e.offset + e.numel].view(e.shape)
-                for e in self._layout.entries if e.cls == STEP}
+        src = {STEP: flat, STEP_F64: flat64}
+        return {e.name: src[e.cls][e.offset:e.offset + e.numel].view(e.shape)
+                for e in self._layout.entries if src.get(e.cls) is not None}
 
     @property
     def m_vector(self) -> Dict[str, torch.Tensor]:
-        return self._moment_views(self._m)
+        return self._moment_views(self._m, self._m64)
 
     @property
     def v_vector(self) -> Dict[str, torch.Tensor]:
-        return self._moment_views(self._v)
+        return self._moment_views(self._v, self._v64)
 
     def set_model_chunk_size(self, chunk_size: int):
         """Chunk size in bytes for chunked `get_parameters` (set by the gRPC communicator)."""
@@ -241,7 +246,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._slab.reserve(max(row + 1, int(hint)), preserve=row)
             if row == 0:
                 self._slab.begin_round()
-            self._slab.upload(row, local_model, fill_missing_from=self._flats["f32"])
+            self._slab.upload(row, local_model, fill_missing_from=self._flats)
             if self._slab.has_device_sources:
                 # the caller may overwrite its device tensors as soon as this returns
                 self._slab.wait_uploads()
@@ -289,7 +294,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             if cid in reuse:
                 self._row_of.append(reuse[cid])
                 continue
-            self._slab.upload(nxt, model, fill_missing_from=self._flats["f32"])
+            self._slab.upload(nxt, model, fill_missing_from=self._flats)
             self._row_of.append(nxt)
             nxt += 1
         self._slab.end_round()
@@ -312,14 +317,21 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         with self._lock:
             self._stage(local_models)
             lay = self._layout
-            n = lay.count[STEP]
+            n, n64 = lay.count[STEP], lay.count[STEP_F64]
+            weights = self._client_weights(local_models)
             if self._step_flat is None:
                 self._step_flat = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
             if n:
-                ops.reduce_step(self._rows(len(local_models), 0), self._client_weights(local_models),
+                ops.reduce_step(self._rows(len(local_models), 0), weights,
                                 self._flats["f32"], self._step_flat, n=n)
-            self.step = {e.name: self._step_flat[e.offset:e.offset + e.numel].view(e.shape)
-                         for e in lay.entries if e.cls == STEP}
+            if n64:
+                if self._step_flat64 is None:
+                    self._step_flat64 = torch.empty(n64, dtype=torch.float64, device=self.device)
+                ops.reduce_step(self._rows(len(local_models), lay.seg_byte[STEP_F64]), weights,
+                                self._flats["f64"], self._step_flat64, n=n64)
+            src = {STEP: self._step_flat, STEP_F64: self._step_flat64}
+            self.step = {e.name: src[e.cls][e.offset:e.offset + e.numel].view(e.shape)
+                         for e in lay.entries if e.cls in src}
 
     def _launch_round(self, K: int, weights, fused: bool = True, events=None) -> None:
         """Enqueue one round's kernels over the K staged rows: the fused weighted-step /
@@ -347,6 +359,16 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                                      step_ws=ws, n=n_step, **self._hyper())
                 if events:
                     events[1].record()
+            n64 = lay.count[STEP_F64]
+            if n64:
+                self._ensure_moments()
+                ws = None
+                if K > self._ops.kchunk():
+                    if self._step_flat64 is None:
+                        self._step_flat64 = torch.empty(n64, dtype=torch.float64, device=self.device)
+                    ws = self._step_flat64
+                self._ops.reduce_opt(self._rows(K, lay.seg_byte[STEP_F64]), weights, self._flats["f64"],
+                                     self._m64, self._v64, self._OPT, step_ws=ws, n=n64, **self._hyper())
         else:
             for e in lay.entries:
                 if e.name in self.step:
@@ -360,6 +382,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         if lay.count[MEAN_F32]:
             self._ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), self._flats["f32"][n_step:],
                            n=lay.count[MEAN_F32])
+        if lay.count[MEAN_F64]:
+            self._ops.mean(self._rows(K, lay.seg_byte[MEAN_F64]), self._flats["f64"][lay.count[STEP_F64]:],
+                           n=lay.count[MEAN_F64])
         if lay.count[MEAN_I64]:
             self._ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
         if lay.count[MEAN_I32]:
@@ -489,7 +514,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             st.slab.reserve(K)
             st.slab.begin_round()
             for k, model in enumerate(local_models.values()):
-                st.slab.upload(k, model, fill_missing_from=st.flats["f32"])
+                st.slab.upload(k, model, fill_missing_from=st.flats)
             st.slab.end_round()
             rows = lambda off: [st.slab.row_ptr(k) + off for k in range(K)]
             if lay.count[STEP]:
@@ -498,6 +523,12 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     ws = torch.empty(lay.count[STEP], dtype=torch.float32, device=self.device)
                 ops.reduce_opt(rows(0), self._client_weights(local_models), st.flats["f32"],
                                step_ws=ws, n=lay.count[STEP])
+            if lay.count[STEP_F64]:
+                ws = None
+                if K > ops.kchunk():
+                    ws = torch.empty(lay.count[STEP_F64], dtype=torch.float64, device=self.device)
+                ops.reduce_opt(rows(lay.seg_byte[STEP_F64]), self._client_weights(local_models),
+                               st.flats["f64"], step_ws=ws, n=lay.count[STEP_F64])
             if lay.count[MEAN_I64]:
                 ops.mean(rows(lay.seg_byte[MEAN_I64]), st.flats["i64"], n=lay.count[MEAN_I64])
             if lay.count[MEAN_I32]:
@@ -526,15 +557,20 @@ class FedAvgMAggregator(FedAvgAggregator):
     def _ensure_moments(self):
         if self._v is None:   # fedavgm_aggregator.py:37-45
             self._v = torch.zeros(self._layout.count[STEP], dtype=torch.float32, device=self.device)
+            if self._layout.count[STEP_F64]:
+                self._v64 = torch.zeros(self._layout.count[STEP_F64], dtype=torch.float64, device=self.device)
 
     @_native
     def compute_steps(self, local_models):
         with self._lock:
             FedAvgAggregator.compute_steps(self, local_models)
-            n = self._layout.count[STEP]
-            if n:
+            n, n64 = self._layout.count[STEP], self._layout.count[STEP_F64]
+            if n or n64:
                 self._ensure_moments()
+            if n:
                 ops.server_opt_step(self._step_flat, self._m, self._v, self._OPT, n=n, **self._hyper())
+            if n64:
+                ops.server_opt_step(self._step_flat64, self._m64, self._v64, self._OPT, n=n64, **self._hyper())
 
 
 class _AdaptiveAggregator(FedAvgMAggregator):
@@ -559,6 +595,11 @@ class _AdaptiveAggregator(FedAvgMAggregator):
             self._m = torch.zeros(n, dtype=torch.float32, device=self.device)
             self._v = torch.empty(n, dtype=torch.float32, device=self.device)
             self._ops.fill(self._v, tau ** 2)
+            n64 = self._layout.count[STEP_F64]
+            if n64:
+                self._m64 = torch.zeros(n64, dtype=torch.float64, device=self.device)
+                self._v64 = torch.empty(n64, dtype=torch.float64, device=self.device)
+                self._ops.fill(self._v64, tau ** 2)
 
 
 class FedAdamAggregator(_AdaptiveAggregator):

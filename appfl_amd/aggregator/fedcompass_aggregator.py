@@ -24,7 +24,7 @@ from .. import ops
 from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout
 from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import BaseAggregator, DeviceStateMixin, cfg_get, resolve_device
-from .fedasync_aggregator import staleness_fn_factory
+from .staleness import fedasync_staleness, fedqueue_staleness
 
 
 class _MixAggregator(BaseAggregator, DeviceStateMixin):
@@ -78,6 +78,10 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
             init = dict(first_model)
         self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
                               self.named_parameters)
+        if self._layout.n_f64:
+            raise NotImplementedError(
+                "float64 entries are supported by the FedAvg family, FedAsync and FedBuff; the "
+                "FedCompass / FedQueue mixes take fp32 and integer entries")
         self._flats = self._layout.alloc_state(self.device)
         with torch.no_grad():
             for n, t in init.items():
@@ -143,8 +147,8 @@ class FedCompassAggregator(_MixAggregator):
     def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
         super().__init__(model, aggregator_configs, logger)
         kw = cfg_get(self.aggregator_configs, "staleness_fn_kwargs", None) or {}
-        self.staleness_fn = staleness_fn_factory(
-            staleness_fn_name=cfg_get(self.aggregator_configs, "staleness_fn", "constant"), **dict(kw))
+        self.staleness_fn = fedasync_staleness(
+            cfg_get(self.aggregator_configs, "staleness_fn", "constant"), **dict(kw))
         self.alpha = cfg_get(self.aggregator_configs, "alpha", 0.9)
 
     def aggregate(self, client_id: Optional[Union[str, int]] = None,
@@ -184,20 +188,6 @@ class FedCompassAggregator(_MixAggregator):
             return self._finish()
 
 
-def _queue_staleness_fn_factory(staleness_fn_name, **kwargs):
-    """fedqueue_aggregator.py:177-191."""
-    if staleness_fn_name == "constant":
-        return lambda u: 1.0
-    elif staleness_fn_name == "harmonic":
-        beta = kwargs["beta"]
-        return lambda u: 1.0 / (1.0 + beta * u)
-    elif staleness_fn_name == "exponential":
-        beta = kwargs["beta"]
-        return lambda u: torch.exp(-beta * u)
-    else:
-        raise NotImplementedError
-
-
 class FedQueueAggregator(_MixAggregator):
     """FedQueue: data-size client weights with staleness decay, normalised over the group.
     Configuration fields: `staleness_fn` (constant | harmonic | exponential),
@@ -206,23 +196,24 @@ class FedQueueAggregator(_MixAggregator):
     def __init__(self, model=None, aggregator_configs: Any = None, logger=None):
         super().__init__(model, aggregator_configs, logger)
         kw = cfg_get(self.aggregator_configs, "staleness_fn_kwargs", None) or {}
-        self.staleness_fn = _queue_staleness_fn_factory(
+        self.staleness_fn = fedqueue_staleness(
             cfg_get(self.aggregator_configs, "staleness_fn", "constant"), **dict(kw))
 
     def _get_aggregation_factors(self, local_models, staleness) -> Dict:
-        """fedqueue_aggregator.py:138-169."""
+        """Un-normalised factor per client: s(staleness) x its share of the group's samples, or
+        x 1/K when a sample size is unknown or they sum to zero (fedqueue_aggregator.py:138-169)."""
         sizes = getattr(self, "client_sample_size", None)
+        share = None
         if sizes is not None and all(cid in sizes for cid in local_models):
             total = sum(sizes[cid] for cid in local_models)
             if total > 0:
-                return {cid: self.staleness_fn(staleness[cid]) * (sizes[cid] / total)
-                        for cid in local_models}
-        if self.logger is not None:
-            self.logger.warning(
-                "FedQueueAggregator did not receive sample sizes for all participating clients; "
-                "falling back to equal client weights.")
-        return {cid: self.staleness_fn(staleness[cid]) * (1.0 / len(local_models))
-                for cid in local_models}
+                share = {cid: sizes[cid] / total for cid in local_models}
+        if share is None:
+            if self.logger is not None:
+                self.logger.warning("FedQueueAggregator: sample sizes missing for some clients of "
+                                    "this group; weighting them equally.")
+            share = {cid: 1.0 / len(local_models) for cid in local_models}
+        return {cid: self.staleness_fn(staleness[cid]) * share[cid] for cid in local_models}
 
     def aggregate(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict]],
                   staleness: Dict[Union[str, int], int],

@@ -981,7 +981,8 @@ inline unsigned grid_for(size_t work_items) {
 constexpr size_t kSegment = size_t(1) << 29;
 
 // Launch shape of the 128-bit reduce kernel.  The defaults are the measured best on MI355X;
-// fa_tune() swaps them at run time so a benchmark can compare shapes inside one process.
+// fa_tune() swaps them at run time, for the CALLING THREAD only, so a benchmark can compare
+// shapes inside one process without touching what other threads' aggregators launch.
 struct Shape {
     int vpt;         // 16-byte vectors per thread per tile: 1, 2 or 4
     int unroll;      // clients loaded ahead of the arithmetic: 4, 8 or 16
@@ -991,12 +992,12 @@ struct Shape {
                      // tiles per CU (0: never, < 0: always); it pays off once every CU has
                      // several tiles of its own
 };
-Shape g_shape = {0, 8, 1, kMaxBlocks, 2};
+thread_local Shape g_shape = {0, 8, 1, kMaxBlocks, 2};
 constexpr unsigned kLeanTileVectors = 1u << 20;   // 16 MiB of g
-int g_write_through = 1;   // fa_tune's nt field: bit 1 set = plain result stores
-int g_interleave = 1;      // fa_tune's nt field: bit 2 set = contiguous per-block ranges in the persistent kernel
-int g_phase_tiles = 0;     // fa_tune's nt field, bits 8-12: tiles per phase of the persistent kernel (0: chosen per launch)
-int g_sync = 2;            // fa_tune's nt field: chip-wide write phases of the persistent kernel -- default: the
+thread_local int g_write_through = 1;   // fa_tune's nt field: bit 1 set = plain result stores
+thread_local int g_interleave = 1;      // fa_tune's nt field: bit 2 set = contiguous per-block ranges in the persistent kernel
+thread_local int g_phase_tiles = 0;     // fa_tune's nt field, bits 8-12: tiles per phase of the persistent kernel (0: chosen per launch)
+thread_local int g_sync = 2;            // fa_tune's nt field: chip-wide write phases of the persistent kernel -- default: the
                            // blocks meet before their bursts; bit 4 set = no phases; bit 5 set = they also
                            // meet after the bursts have drained
 

@@ -4,16 +4,18 @@ The aggregation kernels work on flat vectors, one per arithmetic class:
 
 * ``step``     fp32 entries that take the weighted step (and the server optimizer)
 * ``mean_f32`` fp32 entries that take the plain mean (non-parameters when a model was given)
+* ``step_f64`` / ``mean_f64`` the same two classes for float64 entries
 * ``mean_i64`` / ``mean_i32`` integer entries (plain mean with truncating division)
 
 (classification: algorithm/aggregator/fedavg_aggregator.py:333-340 of the reference.)
 
 A client's state dict is packed into one ROW of bytes with the segments in that order::
 
-    [ step fp32 ... | mean fp32 ... | pad to 16 | int64 ... | int32 ... | pad to 256 ]
+    [ step fp32 ... | mean fp32 ... | pad to 16 | step fp64 ... | mean fp64 ... | int64 ... | int32 ... | pad to 256 ]
 
 so the fp32 part of every row is one contiguous, 16-byte aligned vector whose first ``n_step``
-elements are the weighted class, and the global state uses the same offsets.
+elements are the weighted class (likewise the fp64 part), and the global state uses the same
+offsets.
 """
 
 from __future__ import annotations
@@ -24,9 +26,12 @@ from typing import Dict, Iterable, List, Optional, Sequence, Set, Tuple
 import torch
 
 STEP, MEAN_F32, MEAN_I64, MEAN_I32 = "step", "mean_f32", "mean_i64", "mean_i32"
-_ITEMSIZE = {STEP: 4, MEAN_F32: 4, MEAN_I64: 8, MEAN_I32: 4}
-_DTYPE = {STEP: torch.float32, MEAN_F32: torch.float32, MEAN_I64: torch.int64,
-          MEAN_I32: torch.int32}
+STEP_F64, MEAN_F64 = "step_f64", "mean_f64"
+CLASSES = (STEP, MEAN_F32, STEP_F64, MEAN_F64, MEAN_I64, MEAN_I32)      # order inside a row
+STEP_CLASSES = (STEP, STEP_F64)
+_ITEMSIZE = {STEP: 4, MEAN_F32: 4, STEP_F64: 8, MEAN_F64: 8, MEAN_I64: 8, MEAN_I32: 4}
+_DTYPE = {STEP: torch.float32, MEAN_F32: torch.float32, STEP_F64: torch.float64,
+          MEAN_F64: torch.float64, MEAN_I64: torch.int64, MEAN_I32: torch.int32}
 ROW_ALIGN = 256
 
 
@@ -53,10 +58,12 @@ def classify(dtype: torch.dtype, is_parameter: bool) -> str:
         return MEAN_I64
     if dtype == torch.int32:
         return MEAN_I32
+    if dtype == torch.float64:
+        return STEP_F64 if is_parameter else MEAN_F64
     if dtype != torch.float32:
         raise NotImplementedError(
             f"state-dict entries of dtype {dtype} are not supported by the MI355X aggregation "
-            "kernels (fp32, int64 and int32 are); there is no CPU fallback")
+            "kernels (fp32, fp64, int64 and int32 are); there is no CPU fallback")
     return STEP if is_parameter else MEAN_F32
 
 
@@ -65,18 +72,16 @@ class Layout:
 
     def __init__(self, names_shapes_dtypes: Sequence[Tuple[str, Tuple[int, ...], torch.dtype]],
                  named_parameters: Optional[Set[str]] = None):
-        order = {STEP: [], MEAN_F32: [], MEAN_I64: [], MEAN_I32: []}
+        order = {c: [] for c in CLASSES}
         for name, shape, dtype in names_shapes_dtypes:
             is_param = named_parameters is None or name in named_parameters
             order[classify(dtype, is_param)].append((name, tuple(shape), dtype))
         self.count = {c: sum(_numel(s) for _, s, _ in order[c]) for c in order}
         self.n_f32 = self.count[STEP] + self.count[MEAN_F32]
-        self.seg_byte = {STEP: 0, MEAN_F32: 4 * self.count[STEP]}
-        self.seg_byte[MEAN_I64] = _round_up(4 * self.n_f32, 16)
-        self.seg_byte[MEAN_I32] = self.seg_byte[MEAN_I64] + 8 * self.count[MEAN_I64]
-        self.row_bytes = _round_up(self.seg_byte[MEAN_I32] + 4 * self.count[MEAN_I32], ROW_ALIGN)
+        self.n_f64 = self.count[STEP_F64] + self.count[MEAN_F64]
+        self._place_segments()
         by_name: Dict[str, Entry] = {}
-        for c in (STEP, MEAN_F32, MEAN_I64, MEAN_I32):
+        for c in CLASSES:
             off = 0
             for name, shape, dtype in order[c]:
                 n = _numel(shape)
@@ -88,21 +93,42 @@ class Layout:
         self.by_name = by_name
         self.names = [e.name for e in self.entries]
 
+    def _place_segments(self) -> None:
+        """Byte offsets of the class segments inside a row, from `count` / `n_f32` / `n_f64`."""
+        self.seg_byte = {STEP: 0, MEAN_F32: 4 * self.count[STEP]}
+        self.seg_byte[STEP_F64] = _round_up(4 * self.n_f32, 16)
+        self.seg_byte[MEAN_F64] = self.seg_byte[STEP_F64] + 8 * self.count[STEP_F64]
+        self.seg_byte[MEAN_I64] = self.seg_byte[STEP_F64] + 8 * self.n_f64
+        self.seg_byte[MEAN_I32] = self.seg_byte[MEAN_I64] + 8 * self.count[MEAN_I64]
+        self.row_bytes = _round_up(self.seg_byte[MEAN_I32] + 4 * self.count[MEAN_I32], ROW_ALIGN)
+
     # -- flat views ---------------------------------------------------------------------------
     def alloc_state(self, device) -> Dict[str, torch.Tensor]:
-        """Flat global-state vectors: 'f32' (step segment first, then mean_f32), 'i64', 'i32'."""
+        """Flat global-state vectors: 'f32' (step segment first, then mean_f32), 'f64' (same),
+        'i64', 'i32'."""
         return {
             "f32": torch.zeros(max(self.n_f32, 1), dtype=torch.float32, device=device),
+            "f64": torch.zeros(max(self.n_f64, 1), dtype=torch.float64, device=device),
             "i64": torch.zeros(max(self.count[MEAN_I64], 1), dtype=torch.int64, device=device),
             "i32": torch.zeros(max(self.count[MEAN_I32], 1), dtype=torch.int32, device=device),
         }
 
     @staticmethod
     def flat_key(cls: str) -> str:
-        return {STEP: "f32", MEAN_F32: "f32", MEAN_I64: "i64", MEAN_I32: "i32"}[cls]
+        return {STEP: "f32", MEAN_F32: "f32", STEP_F64: "f64", MEAN_F64: "f64", MEAN_I64: "i64",
+                MEAN_I32: "i32"}[cls]
+
+    def flat_sizes(self) -> Dict[str, int]:
+        """Elements of each flat vector that hold entries."""
+        return {"f32": self.n_f32, "f64": self.n_f64, "i64": self.count[MEAN_I64],
+                "i32": self.count[MEAN_I32]}
 
     def flat_offset(self, e: Entry) -> int:
-        return e.offset + (self.count[STEP] if e.cls == MEAN_F32 else 0)
+        if e.cls == MEAN_F32:
+            return e.offset + self.count[STEP]
+        if e.cls == MEAN_F64:
+            return e.offset + self.count[STEP_F64]
+        return e.offset
 
     def view(self, flats: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
         e = self.by_name[name]
@@ -141,6 +167,8 @@ class WindowedLayout(Layout):
     def __init__(self, full: Layout, windows: Sequence[Tuple[int, int, int]], storage: int):
         if storage % 4:
             raise ValueError("step storage must be a multiple of 4 elements (16 bytes)")
+        if full.n_f64:
+            raise NotImplementedError("float64 entries are not sharded; use the single-GPU aggregators")
         self.full = full
         self.count = dict(full.count)
         self.count[STEP] = storage
@@ -148,10 +176,8 @@ class WindowedLayout(Layout):
         if self.live_step > storage:
             raise ValueError("windows exceed the step storage")
         self.n_f32 = storage + full.count[MEAN_F32]
-        self.seg_byte = {STEP: 0, MEAN_F32: 4 * storage}
-        self.seg_byte[MEAN_I64] = _round_up(4 * self.n_f32, 16)
-        self.seg_byte[MEAN_I32] = self.seg_byte[MEAN_I64] + 8 * self.count[MEAN_I64]
-        self.row_bytes = _round_up(self.seg_byte[MEAN_I32] + 4 * self.count[MEAN_I32], ROW_ALIGN)
+        self.n_f64 = 0
+        self._place_segments()
         self.entries = []
         for e in full.entries:
             if e.cls != STEP:

@@ -53,6 +53,13 @@ def _check_rows(x: Sequence, n: int, dtype) -> "C.Array":
     return N.ptr_array(ptrs)
 
 
+def _float_entry(name: str, t: torch.Tensor):
+    """(entry point, dtype) of the fp32 or fp64 flavour of a flat kernel, by `t`'s dtype."""
+    if t.dtype == torch.float64:
+        return getattr(N.load(), name + "_f64"), torch.float64
+    return getattr(N.load(), name), torch.float32
+
+
 def kchunk() -> int:
     return N.load().fa_kchunk()
 
@@ -77,11 +84,11 @@ def reduce_opt(x: Sequence[torch.Tensor], w: Sequence[float], g: torch.Tensor,
     for t in (m, v, step_out, step_ws):
         if t is not None and t.numel() < n:
             raise ValueError("state / workspace tensor shorter than n")
-    rc = N.load().fa_reduce_opt(
-        _check_rows(x, n, torch.float32), N.double_array([float(t) for t in w]), len(x),
-        _dev(g, torch.float32), _dev(m, torch.float32), _dev(v, torch.float32), n,
-        OPT_CODES[opt], float(lr), float(beta1), float(beta2), float(tau),
-        _dev(step_out, torch.float32), _dev(step_ws, torch.float32), _stream(g))
+    fn, dt = _float_entry("fa_reduce_opt", g)
+    rc = fn(_check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x),
+            _dev(g, dt), _dev(m, dt), _dev(v, dt), n,
+            OPT_CODES[opt], float(lr), float(beta1), float(beta2), float(tau),
+            _dev(step_out, dt), _dev(step_ws, dt), _stream(g))
     N.check(rc, "fa_reduce_opt")
 
 
@@ -105,10 +112,9 @@ def reduce_step(x, w, g, step_out, n: Optional[int] = None) -> None:
     n = g.numel() if n is None else n
     if step_out.numel() < n:
         raise ValueError("step_out shorter than n")
-    rc = N.load().fa_reduce_step(_check_rows(x, n, torch.float32),
-                                 N.double_array([float(t) for t in w]), len(x),
-                                 _dev(g, torch.float32), _dev(step_out, torch.float32), n,
-                                 _stream(g))
+    fn, dt = _float_entry("fa_reduce_step", g)
+    rc = fn(_check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x),
+            _dev(g, dt), _dev(step_out, dt), n, _stream(g))
     N.check(rc, "fa_reduce_step")
 
 
@@ -119,9 +125,9 @@ def server_opt_step(step, m, v, opt: str, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
     for t in (m, v):
         if t is not None and t.numel() < n:
             raise ValueError("moment tensor shorter than n")
-    rc = N.load().fa_server_opt_step(_dev(step, torch.float32), _dev(m, torch.float32),
-                                     _dev(v, torch.float32), n, OPT_CODES[opt], float(lr),
-                                     float(beta1), float(beta2), float(tau), _stream(step))
+    fn, dt = _float_entry("fa_server_opt_step", step)
+    rc = fn(_dev(step, dt), _dev(m, dt), _dev(v, dt), n, OPT_CODES[opt], float(lr),
+            float(beta1), float(beta2), float(tau), _stream(step))
     N.check(rc, "fa_server_opt_step")
 
 
@@ -129,8 +135,8 @@ def apply_step(g, step, n: Optional[int] = None) -> None:
     n = g.numel() if n is None else n
     if step.numel() < n:
         raise ValueError("step shorter than n")
-    N.check(N.load().fa_apply_step(_dev(g, torch.float32), _dev(step, torch.float32), n,
-                                   _stream(g)), "fa_apply_step")
+    fn, dt = _float_entry("fa_apply_step", g)
+    N.check(fn(_dev(g, dt), _dev(step, dt), n, _stream(g)), "fa_apply_step")
 
 
 MIX_MODES = {"replace": 0, "convex": 1, "subtract": 2, "convex_one": 3, "sum_add": 4,
@@ -150,11 +156,12 @@ def weighted_mix(x: Sequence, w: Sequence[float], g: torch.Tensor, mode: str, co
     N.check(rc, "fa_weighted_mix")
 
 
-_MEAN = {torch.float32: "fa_mean_f32", torch.int64: "fa_mean_i64", torch.int32: "fa_mean_i32"}
-_RAW = {torch.float32: "fa_buff_accum_raw_f32", torch.int64: "fa_buff_accum_raw_i64",
-        torch.int32: "fa_buff_accum_raw_i32"}
-_FLUSH = {torch.float32: "fa_buff_flush_mean_f32", torch.int64: "fa_buff_flush_mean_i64",
-          torch.int32: "fa_buff_flush_mean_i32"}
+_MEAN = {torch.float32: "fa_mean_f32", torch.float64: "fa_mean_f64", torch.int64: "fa_mean_i64",
+         torch.int32: "fa_mean_i32"}
+_RAW = {torch.float32: "fa_buff_accum_raw_f32", torch.float64: "fa_buff_accum_raw_f64",
+        torch.int64: "fa_buff_accum_raw_i64", torch.int32: "fa_buff_accum_raw_i32"}
+_FLUSH = {torch.float32: "fa_buff_flush_mean_f32", torch.float64: "fa_buff_flush_mean_f64",
+          torch.int64: "fa_buff_flush_mean_i64", torch.int32: "fa_buff_flush_mean_i32"}
 
 
 def mean(x: Sequence[torch.Tensor], g: torch.Tensor, n: Optional[int] = None) -> None:
@@ -169,9 +176,9 @@ def async_mix(x, alpha_t: float, g, gradient_based: bool = False, sub_form: bool
     n = g.numel() if n is None else n
     if x.numel() < n:
         raise ValueError("x shorter than n")
-    rc = N.load().fa_async_mix(_dev(x, torch.float32), float(alpha_t), int(bool(gradient_based)),
-                               int(bool(sub_form)), _dev(g, torch.float32),
-                               _dev(step_out, torch.float32), n, _stream(g))
+    fn, dt = _float_entry("fa_async_mix", g)
+    rc = fn(_dev(x, dt), float(alpha_t), int(bool(gradient_based)), int(bool(sub_form)), _dev(g, dt),
+            _dev(step_out, dt), n, _stream(g))
     N.check(rc, "fa_async_mix")
 
 
@@ -180,9 +187,9 @@ def buff_accum(x, alpha_t: float, g, step, first: bool, gradient_based: bool = F
     n = g.numel() if n is None else n
     if x.numel() < n or step.numel() < n:
         raise ValueError("x / step shorter than n")
-    fn = N.load().fa_buff_accum_flush if flush else N.load().fa_buff_accum
-    rc = fn(_dev(x, torch.float32), float(alpha_t), int(bool(gradient_based)),
-            _dev(g, torch.float32), _dev(step, torch.float32), int(bool(first)), n, _stream(g))
+    fn, dt = _float_entry("fa_buff_accum_flush" if flush else "fa_buff_accum", g)
+    rc = fn(_dev(x, dt), float(alpha_t), int(bool(gradient_based)),
+            _dev(g, dt), _dev(step, dt), int(bool(first)), n, _stream(g))
     N.check(rc, "fa_buff_accum")
 
 
@@ -205,6 +212,12 @@ def buff_flush_mean(g, step, K: int, n: Optional[int] = None) -> None:
 
 def fill(p: torch.Tensor, value: float, n: Optional[int] = None) -> None:
     n = p.numel() if n is None else n
+    if n == 0:
+        return
+    if p.dtype == torch.float64:
+        N.check(N.load().fa_fill_f64(_dev(p, torch.float64), C.c_double(value), n, _stream(p)),
+                "fa_fill_f64")
+        return
     N.check(N.load().fa_fill_f32(_dev(p, torch.float32), C.c_float(value), n, _stream(p)),
             "fa_fill_f32")
 

@@ -99,7 +99,8 @@ class ClientSlab:
         """Pack `state` into row k (`on_window(a, b, event)`, if given, is called after the
         transfer of each window [a, b) of the row has been enqueued; only valid when every entry
         of `state` is a host tensor).  Entries of the layout that `state` lacks and that take the
-        weighted step are filled from `fill_missing_from` (the global fp32 vector), which makes
+        weighted step are filled from `fill_missing_from` (the global flat vectors by key, or the
+        fp32 one alone), which makes
         their difference zero -- the reference skips such a client for that entry
         (fedavg_aggregator.py:360-361); a missing plain-mean entry raises KeyError (:289)."""
         lay = self.layout
@@ -114,7 +115,7 @@ class ClientSlab:
             if t is None:
                 t = state.get(e.name)
                 if t is None:
-                    if e.cls != "step":
+                    if e.cls not in ("step", "step_f64"):
                         raise KeyError(e.name)
                     missing.append(e)
                     continue
@@ -169,8 +170,10 @@ class ClientSlab:
                     t.record_stream(self.copy_stream)
             for e in missing:
                 off = lay.flat_offset(e)
+                src = (fill_missing_from[lay.flat_key(e.cls)] if isinstance(fill_missing_from, dict)
+                       else fill_missing_from)
                 self.row_view(k, e.byte_offset, e.numel, e.dtype).copy_(
-                    fill_missing_from[off:off + e.numel], non_blocking=True)
+                    src[off:off + e.numel], non_blocking=True)
             ev = self._copy_event()
         self.slot_free[slot] = ev
         self.last_copy = ev

@@ -129,11 +129,15 @@ def _stored_range(buf: memoryview, info: zipfile.ZipInfo) -> Tuple[int, int]:
     if info.compress_type != zipfile.ZIP_STORED:
         raise WireFormatError("compressed archive members are not supported")
     h = info.header_offset
+    if h < 0 or info.file_size < 0 or h + 30 > len(buf):
+        raise WireFormatError("archive member outside the buffer")
     sig, = struct.unpack_from("<I", buf, h)
     if sig != 0x04034B50:
         raise WireFormatError("bad local file header")
     name_len, extra_len = struct.unpack_from("<HH", buf, h + 26)
     start = h + 30 + name_len + extra_len
+    if start + info.file_size > len(buf):
+        raise WireFormatError("archive member reaches past the buffer")
     return start, start + info.file_size
 
 
@@ -151,7 +155,18 @@ def bytes_to_model(model_bytes: Union[bytes, bytearray, memoryview]) -> Dict[str
     of `model_bytes` (which must stay alive as long as they are used); anything else (strided
     tensors, unaligned storages) is copied.  Drop-in for `ServerAgent._bytes_to_model` when
     compression is off."""
-    buf = memoryview(model_bytes).cast("B")
+    try:
+        return _bytes_to_model(memoryview(model_bytes).cast("B"))
+    except WireFormatError:
+        raise
+    except (struct.error, pickle.UnpicklingError, zipfile.BadZipFile, zipfile.LargeZipFile, EOFError,
+            AttributeError, IndexError, KeyError, TypeError, ValueError, RuntimeError, OverflowError,
+            NotImplementedError) as e:
+        # malformed or unusual archives must take the caller's safe fallback, not escape
+        raise WireFormatError(f"cannot read the archive in place: {type(e).__name__}: {e}") from e
+
+
+def _bytes_to_model(buf: memoryview) -> Dict[str, torch.Tensor]:
     try:
         zf = zipfile.ZipFile(_BufferFile(buf))
     except zipfile.BadZipFile as e:
@@ -181,6 +196,9 @@ def _fill_views(out, obj, buf, members, prefix) -> None:
         if member is None:
             raise WireFormatError(f"storage {ref.storage.key} missing from the archive")
         s0, s1 = _stored_range(buf, member)
+        if (ref.storage.numel < 0 or ref.offset < 0 or any(d < 0 for d in ref.size)
+                or any(d < 0 for d in ref.stride) or len(ref.size) != len(ref.stride)):
+            raise WireFormatError(f"entry {name!r} has a negative or inconsistent size, stride or offset")
         item = torch.empty((), dtype=ref.storage.dtype).element_size()
         if s1 - s0 < ref.storage.numel * item:
             raise WireFormatError(f"storage {ref.storage.key} is truncated")
@@ -196,6 +214,9 @@ def _fill_views(out, obj, buf, members, prefix) -> None:
             t = torch.frombuffer(buf, dtype=ref.storage.dtype, count=numel, offset=start)
             out[name] = t.view(ref.size)
         else:
+            last = ref.offset + sum((d - 1) * st for d, st in zip(ref.size, ref.stride))
+            if last >= ref.storage.numel:
+                raise WireFormatError(f"entry {name!r} reaches past its storage")
             whole = torch.frombuffer(buf, dtype=ref.storage.dtype, count=ref.storage.numel, offset=s0)
             out[name] = torch.as_strided(whole, ref.size, ref.stride, ref.offset).clone()
 

@@ -73,7 +73,7 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * on a launch with a long client list (FedAvg >= 32, FedAvgM >= 48 clients) takes the persistent
  * kernel that parks results in LDS and writes them in bursts (stash: 0 never, < 0 always for
  * more than 8 clients, default 2).  Results do not depend on it.
- * Process-wide; not synchronised with concurrent calls.
+ * Applies to launches made by the calling thread only (thread-local state).
  */
 int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);
 
@@ -218,6 +218,33 @@ int fa_buff_flush_mean_i64(int64_t* g, const int64_t* step, int K, size_t n,
                            fa_stream_t stream);
 int fa_buff_flush_mean_i32(int32_t* g, const int32_t* step, int K, size_t n,
                            fa_stream_t stream);
+
+/*
+ * The same steps for float64 entries of a state dict.  The reference's float path takes any
+ * float tensor (misc/memory_utils.py:112-131; the formulas are those cited at the fp32 entry
+ * points of the same names); for float64 tensors PyTorch keeps Python scalars in double, so w,
+ * alpha_t and the hyper-parameters enter as the doubles they are (no rounding to fp32), and
+ * every operation is a separately rounded IEEE double operation in the same order.  Buffers
+ * must be 8-byte aligned.
+ */
+int fa_reduce_opt_f64(const double* const* x, const double* w, int K, double* g, double* m, double* v,
+                      size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                      double* step_out, double* step_ws, fa_stream_t stream);
+int fa_reduce_step_f64(const double* const* x, const double* w, int K, const double* g, double* step_out,
+                       size_t n, fa_stream_t stream);
+int fa_server_opt_step_f64(double* step, double* m, double* v, size_t n, int opt, double lr, double beta1,
+                           double beta2, double tau, fa_stream_t stream);
+int fa_apply_step_f64(double* g, const double* step, size_t n, fa_stream_t stream);
+int fa_mean_f64(const double* const* x, int K, double* g, size_t n, fa_stream_t stream);
+int fa_async_mix_f64(const double* x, double alpha_t, int gradient_based, int sub_form, double* g,
+                     double* step_out, size_t n, fa_stream_t stream);
+int fa_buff_accum_f64(const double* x, double alpha_t, int gradient_based, const double* g, double* step,
+                      int first, size_t n, fa_stream_t stream);
+int fa_buff_accum_flush_f64(const double* x, double alpha_t, int gradient_based, double* g, double* step,
+                            int first, size_t n, fa_stream_t stream);
+int fa_buff_accum_raw_f64(const double* x, double* step, int first, size_t n, fa_stream_t stream);
+int fa_buff_flush_mean_f64(double* g, const double* step, int K, size_t n, fa_stream_t stream);
+int fa_fill_f64(double* p, double value, size_t n, fa_stream_t stream);
 
 /* p[i] = value: moment initialisation (m = 0, v = (float)(tau**2), fedadam_aggregator.py:45-49). */
 int fa_fill_f32(float* p, float value, size_t n, fa_stream_t stream);

@@ -88,6 +88,15 @@ def test_errors_match_reference():
         agg.aggregate({0: S.make_state(S.TOY, seed=1), 1: S.make_state(S.TOY, seed=2)})
 
 
+def test_fedqueue_exponential_fails_like_the_reference():
+    """fedqueue_aggregator.py:189-191 calls torch.exp on a Python number: constructing works,
+    the first aggregation raises TypeError.  Same here, on purpose."""
+    import appfl_amd.aggregator as A
+    agg = A.FedQueueAggregator(None, {"staleness_fn": "exponential", "staleness_fn_kwargs": {"beta": 0.5}}, None)
+    with pytest.raises(TypeError):
+        agg.aggregate({0: S.make_state(S.TOY, seed=1)}, {0: 1}, {0: 3})
+
+
 def test_user_subclass_overriding_compute_steps():
     """A plugin that post-processes self.step (as the reference's subclasses do) still works:
     aggregate() falls back to compute_steps() -> apply."""

@@ -147,3 +147,25 @@ def test_pack_host_window_and_fresh_copy():
     assert N.load().fa_host_copy_fresh(C.c_void_p(fresh.ctypes.data), C.c_void_p(src.ctypes.data),
                                        fresh.size, 6) == 0
     assert np.array_equal(fresh, src)
+
+
+def test_staleness_functions_and_their_errors():
+    """Host scalars of the asynchronous aggregators (fedasync_aggregator.py:266-277,
+    fedqueue_aggregator.py:177-191): same doubles, same exceptions -- including the reference's
+    un-runnable 'exponential' FedQueue function, which raises TypeError when called."""
+    from appfl_amd.aggregator.staleness import fedasync_staleness, fedqueue_staleness
+    assert [fedasync_staleness("constant")(u) for u in (0, 3)] == [1, 1]
+    assert fedasync_staleness("polynomial", a=0.5)(3) == (3 + 1) ** (-0.5)
+    hinge = fedasync_staleness("hinge", a=10, b=2)
+    assert hinge(2) == 1 and hinge(5) == 1.0 / (10 * (5 - 2) + 1.0)
+    assert fedqueue_staleness("harmonic", beta=0.5)(4) == 1.0 / (1.0 + 0.5 * 4)
+    assert fedqueue_staleness("constant")(9) == 1.0
+    with pytest.raises(NotImplementedError):
+        fedasync_staleness("nope")
+    with pytest.raises(NotImplementedError):
+        fedqueue_staleness("polynomial", a=1)
+    with pytest.raises(KeyError):
+        fedasync_staleness("hinge", a=1)
+    exp = fedqueue_staleness("exponential", beta=0.1)        # building it works, as in the reference
+    with pytest.raises(TypeError):
+        exp(2)

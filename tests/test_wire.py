@@ -118,3 +118,29 @@ def test_crc32_combine_matches_zlib():
     a, b = bytes(range(256)) * 37, b"federated" * 1001
     assert wire.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
     assert wire.crc32_combine(zlib.crc32(a), zlib.crc32(b""), 0) == zlib.crc32(a)
+
+
+def test_corrupted_archives_raise_wire_format_error_only():
+    """Whatever is wrong with a payload, bytes_to_model raises WireFormatError (so callers take
+    their torch.load fallback) and nothing else."""
+    import io
+    import struct
+    state = {"w": torch.arange(12, dtype=torch.float32).reshape(3, 4), "n": torch.tensor(3)}
+    buf = io.BytesIO()
+    torch.save(state, buf)
+    good = buf.getvalue()
+    assert torch.equal(wire.bytes_to_model(good)["w"], state["w"])
+    bad_cases = [good[: len(good) // 2], good[:-30] + b"\x00" * 30, b"", b"PK\x03\x04" + b"\x00" * 40]
+    # a central-directory size that does not match the archive
+    cd = good.rfind(b"PK\x01\x02")
+    bad_cases.append(good[:cd + 20] + struct.pack("<II", 2 ** 31, 2 ** 31) + good[cd + 28:])
+    # garbage in the pickle stream
+    p = good.find(b"data.pkl") + len("data.pkl")
+    bad_cases.append(good[:p + 40] + bytes(reversed(good[p + 40:p + 90])) + good[p + 90:])
+    for blob in bad_cases:
+        try:
+            out = wire.bytes_to_model(blob)
+        except wire.WireFormatError:
+            continue
+        # a corruption that happens to leave a readable archive must still give tensors
+        assert all(isinstance(t, torch.Tensor) for t in out.values())

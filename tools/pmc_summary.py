@@ -45,6 +45,27 @@ def main():
         sub = m.group(1) if m else top["Name"]
         kname, fetch_kib, nf = counter_avg(os.path.join(d, "fetch", "f_counter_collection.csv"), "FETCH_SIZE", sub)
         _, write_kib, nw = counter_avg(os.path.join(d, "write", "w_counter_collection.csv"), "WRITE_SIZE", sub)
+        extra = {}
+        for sub_dir, pre, names in (("stall", "s", ("TCC_EA0_WRREQ_STALL_sum", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum",
+                                                    "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum", "TCC_CYCLE_sum",
+                                                    "GRBM_GUI_ACTIVE")),
+                                    ("l2", "h", ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_LEVEL_sum",
+                                                 "TCC_EA0_RDREQ_sum"))):
+            path = os.path.join(d, sub_dir, f"{pre}_counter_collection.csv")
+            if os.path.exists(path):
+                for cname in names:
+                    try:
+                        extra[cname] = counter_avg(path, cname, sub)[1]
+                    except ValueError:
+                        pass
+        if "TCC_HIT_sum" in extra and "TCC_MISS_sum" in extra:
+            extra["l2_hit_rate"] = extra["TCC_HIT_sum"] / max(1.0, extra["TCC_HIT_sum"] + extra["TCC_MISS_sum"])
+        if "TCC_CYCLE_sum" in extra:
+            for k in ("TCC_EA0_WRREQ_STALL_sum", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum", "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum"):
+                if k in extra:
+                    extra[k.replace("_sum", "_per_cycle")] = extra[k] / extra["TCC_CYCLE_sum"]
+        if "TCC_EA0_RDREQ_LEVEL_sum" in extra and extra.get("TCC_EA0_RDREQ_sum"):
+            extra["read_latency_l2_cycles"] = extra["TCC_EA0_RDREQ_LEVEL_sum"] / extra["TCC_EA0_RDREQ_sum"]
         rec = {
             "workload": wl, "kernel": kname,
             "kernel_avg_ns": float(top["AverageNs"]), "kernel_calls": int(top["Calls"]),
@@ -54,6 +75,7 @@ def main():
             "hbm_write_bytes_per_launch": write_kib * 1024,
             "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
             "correction": "FETCH_SIZE doubled (gfx950 counts 128-B streaming read requests at 64 B)",
+            "l2_fabric_counters_per_launch": extra,
         }
         json.dump(rec, open(os.path.join(prof, f"{tag}_{wl}_pmc.json"), "w"), indent=1)
         traffic[wl] = {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "source": f"{tag}_{wl}_pmc.json"}
