@@ -47,6 +47,12 @@ def cfg_get(cfg, key, default=None):
     return getattr(cfg, key, default)
 
 
+def _sc(x: float, like: np.ndarray):
+    """A Python float that multiplies / adds to a float tensor takes the TENSOR's precision:
+    rounded to fp32 once for an fp32 tensor, kept as the double it is for a float64 one."""
+    return like.dtype.type(x)
+
+
 def _f32(x: float) -> np.float32:
     """A Python float that multiplies / adds to an fp32 tensor is rounded to fp32 once."""
     return np.float32(x)
@@ -154,11 +160,11 @@ class OracleFedAvg(OracleBase):
                 self.step[name] = np.zeros_like(self.global_state[name])
         w = self._weights(local_models)
         for cid, model in local_models.items():
-            wk = _f32(w[cid])
             for name in model:
                 if name in self.step:
-                    diff = to_np(model[name]).astype(F32, copy=False) - self.global_state[name]
-                    self.step[name] = self.step[name] + diff * wk
+                    g = self.global_state[name]
+                    diff = to_np(model[name]).astype(g.dtype, copy=False) - g
+                    self.step[name] = self.step[name] + diff * _sc(w[cid], g)
 
     def _aggregate_chunk(self, local_models, **kwargs):
         """fedavg_aggregator.py:406-497: streamed aggregation of the keys in `_chunk_keys`."""
@@ -175,10 +181,9 @@ class OracleFedAvg(OracleBase):
                 step[key] = np.zeros_like(self.global_state[key])
         w = self._weights(local_models)
         for cid, model in local_models.items():
-            wk = _f32(w[cid])
             for key in chunk_keys:
                 if key in step and key in model:
-                    step[key] = step[key] + (model[key] - self.global_state[key]) * wk
+                    step[key] = step[key] + (model[key] - self.global_state[key]) * _sc(w[cid], step[key])
         for key in chunk_keys:
             if key in step:
                 self.global_state[key] = self.global_state[key] + step[key]
@@ -260,9 +265,9 @@ class OracleFedAvgM(OracleFedAvg):
         if len(self.v_vector) == 0:
             for name in self.step:
                 self.v_vector[name] = np.zeros_like(self.step[name])
-        b1 = _f32(cfg_get(self.cfg, "server_momentum_param_1"))
+        b1 = cfg_get(self.cfg, "server_momentum_param_1")
         for name in self.step:
-            self.v_vector[name] = self.v_vector[name] * b1 + self.step[name]
+            self.v_vector[name] = self.v_vector[name] * _sc(b1, self.step[name]) + self.step[name]
             self.step[name] = self.v_vector[name].copy()
 
 
@@ -284,14 +289,14 @@ class _OracleAdaptive(OracleFedAvg):
             # fedadam_aggregator.py:41-50: zeros + tau**2 (Python double, rounded to fp32)
             for name in self.step:
                 self.m_vector[name] = np.zeros_like(self.step[name])
-                self.v_vector[name] = np.zeros_like(self.step[name]) + _f32(tau ** 2)
+                self.v_vector[name] = np.zeros_like(self.step[name]) + _sc(tau ** 2, self.step[name])
         beta1 = cfg_get(self.cfg, "server_momentum_param_1")
         beta2 = cfg_get(self.cfg, "server_momentum_param_2", 0.0)
-        b1, omb1 = _f32(beta1), _f32(1 - beta1)
-        b2, omb2 = _f32(beta2), _f32(1 - beta2)
-        lr = _f32(cfg_get(self.cfg, "server_learning_rate"))
         for name in self.step:
             st = self.step[name]
+            b1, omb1 = _sc(beta1, st), _sc(1 - beta1, st)
+            b2, omb2 = _sc(beta2, st), _sc(1 - beta2, st)
+            lr = _sc(cfg_get(self.cfg, "server_learning_rate"), st)
             with np.errstate(all="ignore"):      # inf / nan propagate as in the reference
                 # fedadam_aggregator.py:64-73
                 self.m_vector[name] = self.m_vector[name] * b1 + st * omb1
@@ -300,7 +305,7 @@ class _OracleAdaptive(OracleFedAvg):
                 # fedadam_aggregator.py:89-99.  np.sqrt is the IEEE correctly rounded sqrt; the
                 # reference's torch.sqrt (MKL vector math) may be one ulp lower.
                 num = lr * self.m_vector[name]
-                den = np.sqrt(self.v_vector[name]) + _f32(tau)
+                den = np.sqrt(self.v_vector[name]) + _sc(tau, st)
                 self.step[name] = num / den
 
 
@@ -384,11 +389,11 @@ class OracleFedAsync(OracleBase):
         return self.alpha * self.staleness_fn(self.global_step - self.client_step[client_id]) * weight
 
     def _arrival_step(self, x, g, alpha_t, gradient_based, sub_form):
-        a = _f32(alpha_t)
+        a = _sc(alpha_t, g)
         if not gradient_based:
             return a * (x - g)                 # :253-258 / :263
         if sub_form:
-            return F32(0.0) - a * x            # :246-251  zeros.sub_(x, alpha=a)
+            return g.dtype.type(0.0) - a * x   # :246-251  zeros.sub_(x, alpha=a)
         return a * (-x)                        # :261
 
     def compute_steps(self, client_id, local_model):

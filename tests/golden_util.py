@@ -31,7 +31,9 @@ def record_hash(d) -> str:
 
 def _bits(a):
     a = np.ascontiguousarray(a)
-    return a.view(np.uint32) if a.dtype == np.float32 else a
+    if a.dtype == np.float32:
+        return a.view(np.uint32)
+    return a.view(np.uint64) if a.dtype == np.float64 else a
 
 
 def canonical_nan(a):
@@ -41,7 +43,7 @@ def canonical_nan(a):
     a = np.ascontiguousarray(a)
     if a.dtype.kind == "f" and np.isnan(a).any():
         a = a.copy()
-        a[np.isnan(a)] = np.float32("nan")
+        a[np.isnan(a)] = a.dtype.type("nan")
     return a
 
 

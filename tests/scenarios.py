@@ -38,9 +38,29 @@ RAGGED = {
     "w": ((100003,), "f32"),
 }
 BIG = {"w": ((1000003,), "f32"), "n": ((), "i64")}
-SPECS = {"toy": TOY, "ragged": RAGGED, "big": BIG}
+# float64 parameters and buffers next to fp32 ones (state_dict order of Mixed64Model)
+MIXED64 = {
+    "a.weight": ((6, 4), "f32"),
+    "a.bias": ((6,), "f32"),
+    "bn.weight": ((5,), "f64"),
+    "bn.bias": ((5,), "f64"),
+    "bn.running_mean": ((5,), "f64"),
+    "bn.running_var": ((5,), "f64"),
+    "bn.num_batches_tracked": ((), "i64"),
+    "b.weight": ((37, 5), "f64"),
+    "b.bias": ((37,), "f64"),
+}
+SPECS = {"toy": TOY, "ragged": RAGGED, "big": BIG, "mixed64": MIXED64}
 
-_NP = {"f32": np.float32, "i64": np.int64, "i32": np.int32}
+_NP = {"f32": np.float32, "f64": np.float64, "i64": np.int64, "i32": np.int32}
+
+
+def fill64(n: int, seed: int, scale: float = 1.0, base=None) -> np.ndarray:
+    """float64 values that are not representable in fp32: two fp32 draws, the second scaled
+    down by 2**-25."""
+    a = synth.fill(n, seed, scale=scale).astype(np.float64) + \
+        synth.fill(n, seed + 7919, scale=scale).astype(np.float64) * 2.0 ** -25
+    return a if base is None else base + a
 
 
 class ToyModel(torch.nn.Module):
@@ -61,6 +81,26 @@ class ToyModel(torch.nn.Module):
             self.bn.running_var.abs_().add_(1.0)
 
 
+class Mixed64Model(torch.nn.Module):
+    """fp32 linear -> float64 batch-norm -> float64 linear, with the MIXED64 entry names."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(4, 6)
+        self.bn = torch.nn.BatchNorm1d(5).double()
+        self.b = torch.nn.Linear(5, 37).double()
+        with torch.no_grad():
+            for i, (name, t) in enumerate(self.state_dict().items()):
+                if t.dtype == torch.int64:
+                    t.fill_(3)
+                elif t.dtype == torch.float64:
+                    t.copy_(torch.from_numpy(fill64(t.numel(), 600 + i, scale=0.05).reshape(tuple(t.shape))))
+                else:
+                    t.copy_(torch.from_numpy(
+                        synth.fill(t.numel(), 600 + i, scale=0.05).reshape(tuple(t.shape))))
+            self.bn.running_var.abs_().add_(1.0)
+
+
 def _name_seed(name: str) -> int:
     return sum((i + 1) * ord(c) for i, c in enumerate(name)) % 100000
 
@@ -72,7 +112,16 @@ def make_state(spec: Dict, seed: int, base_seed: int = 7, scale: float = 0.02,
     for name, (shape, kind) in spec.items():
         n = int(np.prod(shape)) if shape else 1
         ns = _name_seed(name)
-        if kind == "f32":
+        if kind == "f64":
+            if gradient:
+                a = fill64(n, seed * 131 + ns, scale=scale)
+            else:
+                a = fill64(n, seed * 131 + ns, scale=scale, base=fill64(n, base_seed * 131 + ns, scale=0.05))
+            if n >= 5:
+                a[1] = 0.0 if gradient else fill64(n, base_seed * 131 + ns, scale=0.05)[1]
+                a[2] = -0.0
+                a[4] = 1e-310                       # a float64 denormal
+        elif kind == "f32":
             if gradient:
                 a = synth.fill(n, seed * 131 + ns, scale=scale)
             else:
@@ -216,7 +265,7 @@ def chunked_scenarios() -> List[Dict]:
 
 def chunk_keys_by_size(spec: Dict, max_bytes: int) -> List[List[str]]:
     """misc/memory_utils.py:317-379: names sorted, greedy fill, oversized tensors alone."""
-    item = {"f32": 4, "i64": 8, "i32": 4}
+    item = {"f32": 4, "f64": 8, "i64": 8, "i32": 4}
     chunks, cur, size = [], [], 0
     for key in sorted(spec):
         shape, kind = spec[key]
@@ -319,9 +368,33 @@ def sched_scenarios() -> List[Dict]:
     return out
 
 
+def float64_scenarios() -> List[Dict]:
+    """State dicts with float64 parameters and buffers beside fp32 ones: the reference's float
+    path takes any float dtype (misc/memory_utils.py:112-131) and PyTorch then keeps the Python
+    scalars (weights, alpha_t, hyper-parameters) in double."""
+    out = []
+    for cls, with_model in itertools.product(SYNC_CLASSES, (False, True)):
+        out.append({"id": f"{cls[:-10]}-f64-{'model' if with_model else 'nomodel'}", "kind": "sync",
+                    "cls": cls, "spec": "mixed64", "model": with_model,
+                    "cfg": dict(HP[cls], client_weights_mode="sample_size"), "rounds": [2, 3, 2],
+                    "sample_sizes": {c: 3 + 8 * c + (c % 3) for c in range(6)}})
+    for cls, with_model, gb in (("FedAsyncAggregator", False, False), ("FedAsyncAggregator", True, True),
+                                ("FedBuffAggregator", True, False), ("FedBuffAggregator", False, True)):
+        cfg = dict(STALENESS["polynomial"], alpha=0.9, num_clients=3, gradient_based=gb)
+        if cls == "FedBuffAggregator":
+            cfg["K"] = 2
+        out.append({"id": f"{cls[:-10]}-f64-{'model' if with_model else 'nomodel'}-{'grad' if gb else 'model'}",
+                    "kind": "async", "cls": cls, "spec": "mixed64", "model": with_model, "cfg": cfg,
+                    "script": ASYNC_SCRIPT[:6], "sample_sizes": {}})
+    out.append({"id": "FedAvg-f64-chunked", "kind": "chunked", "cls": "FedAvgAggregator", "spec": "mixed64",
+                "model": False, "cfg": dict(HP["FedAvgAggregator"], client_weights_mode="equal"),
+                "rounds": [2, 3], "chunk_bytes": 400, "whole_after": [2], "sample_sizes": {}})
+    return out
+
+
 def all_scenarios() -> List[Dict]:
     return (sync_scenarios() + async_scenarios() + chunked_scenarios() + mix_scenarios()
-            + secure_scenarios() + getparams_scenarios() + sched_scenarios())
+            + secure_scenarios() + getparams_scenarios() + sched_scenarios() + float64_scenarios())
 
 
 def _meta_record(meta: Dict) -> Dict[str, np.ndarray]:
@@ -463,7 +536,7 @@ def run_scenario(factory: Callable, sc: Dict, schedulers: Callable = default_sch
     aggregator in the scheduler-driven scenarios (default: the package's stand-ins; the golden
     generator passes the reference's own)."""
     spec = SPECS[sc["spec"]]
-    model = ToyModel() if sc["model"] else None
+    model = (Mixed64Model() if sc["spec"] == "mixed64" else ToyModel()) if sc["model"] else None
     agg = factory(sc["cls"], model, dict(sc["cfg"]))
     for cid, n in sc["sample_sizes"].items():
         agg.set_client_sample_size(cid, n)

@@ -97,6 +97,22 @@ def test_fedqueue_exponential_fails_like_the_reference():
         agg.aggregate({0: S.make_state(S.TOY, seed=1)}, {0: 1}, {0: 3})
 
 
+def test_float64_entries_with_more_clients_than_one_launch_folds():
+    """130 clients (two launches carrying the partial step) of a state dict with float64 and
+    fp32 entries, FedAdam: identical bits to the oracle over two rounds."""
+    import appfl_amd.aggregator as A
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="equal")
+    agg, ora = A.FedAdamAggregator(None, cfg, None), OA.OracleFedAdam(None, cfg, None)
+    spec = {"w64": ((1031,), "f64"), "w32": ((517,), "f32"), "n": ((), "i64")}
+    for r in range(2):
+        local = {c: S.make_state(spec, seed=50 * r + c) for c in range(130)}
+        got = agg.aggregate(local)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
+        for k in want:
+            assert got[k].dtype == local[0][k].dtype
+            assert golden_util.same_bits(got[k].numpy(), want[k]), (r, k)
+
+
 def test_user_subclass_overriding_compute_steps():
     """A plugin that post-processes self.step (as the reference's subclasses do) still works:
     aggregate() falls back to compute_steps() -> apply."""
