@@ -14,8 +14,9 @@ import torch
 from appfl_amd import ops
 
 
-def time_rounds(fns, reps):
-    """fns: list of callables; returns per-fn sorted times (ms), interleaved round-robin."""
+def time_rounds(fns, reps, batch=1):
+    """fns: list of callables; returns per-fn sorted times (ms per call), interleaved round-robin;
+    `batch` calls are enqueued back to back between the two events of one sample."""
     for f in fns:
         f()
     torch.cuda.synchronize()
@@ -24,10 +25,11 @@ def time_rounds(fns, reps):
         for i, f in enumerate(fns):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            f()
+            for _ in range(batch):
+                f()
             b.record()
             b.synchronize()
-            out[i].append(a.elapsed_time(b))
+            out[i].append(a.elapsed_time(b) / batch)
     return [sorted(t) for t in out]
 
 
@@ -37,6 +39,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--pad", type=int, default=0, help="extra floats between client rows")
     ap.add_argument("--shapes", default="4,8,1,65536")
+    ap.add_argument("--batch", type=int, default=1, help="launches per timed sample (small kernels)")
     a = ap.parse_args()
     shapes = [tuple(int(t) for t in s.split(",")) for s in a.shapes.split(";")]
     hp = dict(lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
@@ -64,7 +67,7 @@ def main():
                 else:
                     ops.reduce_opt(xs, w, g, m, v, opt, **hp)
             return f
-        ts = time_rounds([mk(s) for s in shapes], a.reps)
+        ts = time_rounds([mk(s) for s in shapes], a.reps, a.batch)
         print(f"== n={n} K={K} opt={opt} client bytes {K*n*4/1e9:.2f} GB", flush=True)
         for s, t in zip(shapes, ts):
             med, best = t[len(t) // 2], t[0]
