@@ -5,8 +5,11 @@
  * Every pointer named x / g / m / v / step is DEVICE memory unless the comment says "host".
  * Nothing here allocates, frees or synchronises: the caller owns every buffer, every call only
  * enqueues work on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
- * returns.  Calls on one stream execute in order; the library keeps no state between calls, so
- * it is thread-compatible (concurrent calls must use different buffers).
+ * returns.  Calls on one stream execute in order.  The library is thread-compatible
+ * (concurrent calls must use different buffers); the only device state it owns are two
+ * static arrays per GPU: 16 KiB of meeting counters its persistent reduce kernel uses for
+ * timing only (a slot per launch, zeroed on the launch's stream; results never depend on
+ * them) and the workspace of fa_reduce_opt_static.
  *
  * Arithmetic contract: each documented formula is evaluated as separately rounded IEEE fp32
  * operations in the written order (no FMA contraction, correctly rounded / and sqrt, denormals
