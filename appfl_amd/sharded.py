@@ -128,14 +128,25 @@ def round_gather_pipelined(ops, smap: ShardMap, x: Sequence, w: Sequence[float],
     about as long as the local round, so the pipeline hides whichever is shorter."""
     if out.numel() < smap.P:
         raise ValueError("gather buffer shorter than the padded vector")
+    # While a gather is in flight its copy kernels hold some CUs.  The persistent reduce kernel
+    # wants EVERY CU for one block each (all of a CU's LDS and registers), so beside a running
+    # gather its last blocks would wait for the gather to end and the pipeline would serialise;
+    # the tile-per-block kernel (many small blocks, 1 % slower on its own) shares the chip.
+    shared = smap.world > 1 and smap.pieces > 1 and hasattr(ops, "tune")
+    if shared:
+        ops.tune(stash=0)
     works = []
-    for p in range(smap.pieces):
-        a, live = p * smap.per, smap.live(p)
-        if live > 0:
-            ops.reduce_opt([_shift(c, a) for c in x], list(w), g[a:],
-                           None if m is None else m[a:], None if v is None else v[a:], opt,
-                           step_ws=None if step_ws is None else step_ws[a:], n=live, **hp)
-        works += gather_rows(smap, g, out, group, rows=[p], async_op=True)
+    try:
+        for p in range(smap.pieces):
+            a, live = p * smap.per, smap.live(p)
+            if live > 0:
+                ops.reduce_opt([_shift(c, a) for c in x], list(w), g[a:],
+                               None if m is None else m[a:], None if v is None else v[a:], opt,
+                               step_ws=None if step_ws is None else step_ws[a:], n=live, **hp)
+            works += gather_rows(smap, g, out, group, rows=[p], async_op=True)
+    finally:
+        if shared:
+            ops.tune()
     for wk in works:
         wk.wait()
     return out
