@@ -165,4 +165,7 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         if "_chunk_idx" in kwargs:
             raise NotImplementedError("streamed (chunked) aggregation is not sharded; use the "
                                       "single-GPU FedAvgAggregator for it")
+        if any(isinstance(m, dict) and m.get("type") == "masked_update_flat" for m in local_models.values()):
+            raise NotImplementedError("secure-aggregation payloads are not sharded; use the "
+                                      "single-GPU FedAvgAggregator for them")
         return super().aggregate(local_models, **kwargs)

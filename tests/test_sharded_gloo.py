@@ -99,19 +99,17 @@ def test_shard_map_covers_the_vector_exactly_once():
                     pos = hi
                 assert pos == n
                 for m in maps:
-                    # live elements are a prefix of the local storage
-                    loc = 0
-                    for lo, hi, off in m.windows():
-                        assert off == loc or (off % m.per == 0 and loc % m.per == 0 and off == loc)
-                        loc = off + hi - lo
-                        if hi - lo < m.per:
-                            break
-                    assert m.n_local == sum(hi - lo for lo, hi, _ in m.windows())
+                    wins = m.windows()
+                    # live elements are a prefix of the local storage: full blocks, then at most
+                    # one partial block, then nothing
+                    assert [off for _, _, off in wins] == [p * m.per for p in range(len(wins))]
+                    assert all(hi - lo == m.per for lo, hi, _ in wins[:-1])
+                    assert m.n_local == sum(hi - lo for lo, hi, _ in wins)
                     # block (p, r) sits where the in-place gather of row p puts it
                     for p in range(pieces):
-                        a, b = m.row(p)
-                        assert (a + m.rank * m.per, min(n, a + (m.rank + 1) * m.per))[0] == \
-                            (p * world + m.rank) * m.per
+                        a, _ = m.row(p)
+                        lo, _ = m.block(p)
+                        assert lo == min(n, a + m.rank * m.per)
     assert default_pieces(1_300_000_000, 8) == 4 and default_pieces(25_557_032, 8) == 1
     assert default_pieces(1_300_000_000, 2) == 8
 
