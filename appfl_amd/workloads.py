@@ -119,6 +119,7 @@ WORKLOADS: Dict[str, Dict] = {
     "resnet50_fedadam_k64": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 64},
     "resnet50_fedyogi_k64": {"table": lambda: resnet(50), "cls": "FedYogiAggregator", "K": 64},
     "resnet50_fedavg_k64": {"table": lambda: resnet(50), "cls": "FedAvgAggregator", "K": 64},
+    "resnet50_fedavgm_k64": {"table": lambda: resnet(50), "cls": "FedAvgMAggregator", "K": 64},
     "vitb16_fedasync": {"table": vit_b_16, "cls": "FedAsyncAggregator", "K": 1},
     "vitb16_fedbuff_k16": {"table": vit_b_16, "cls": "FedBuffAggregator", "K": 16},
     "flat162m_fedavg_k32": {"table": lambda: flat(162_500_000), "cls": "FedAvgAggregator", "K": 32},
