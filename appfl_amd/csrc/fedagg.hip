@@ -305,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
 // write in PHASES: all of them MEET (grid_meet, a bounded wait that carries no data) before
 // their bursts, each drains its own burst (s_waitcnt vmcnt(0) on write-through stores), and only
 // then issues the loads of the next phase, whose pipeline therefore starts empty.  Worth
-// 2.5-3.5 % on a 650 MB vector over bursts that every block fires on its own; meeting again
+// 6-7 % on a 650 MB vector over bursts that every block fires on its own; meeting again
 // after the bursts, meeting between bursts, or dealing the tiles in groups so that a burst is
 // contiguous, is not.  A vector that the chip can park whole (up to 18 tiles per CU under plain
 // FedAvg) is written in one burst when all its reads are done (+1-2 % over several bursts).
@@ -323,7 +323,7 @@ constexpr int kStashMaxTiles = FA_STASH_MAX_TILES;
 #ifndef FA_STASH_REG_BUDGET
 #define FA_STASH_REG_BUDGET 128
 #endif
-constexpr unsigned kPhaseTiles = 8;   // tiles per phase of a vector too long to be parked whole
+constexpr unsigned kPhaseTiles = 4;   // tiles per phase of a vector too long to be parked whole
 constexpr int kStashRegBudget = FA_STASH_REG_BUDGET;   // registers per lane that may hold parked results
 
 // What a launch writes back per tile.
@@ -441,8 +441,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         const unsigned most = (total + gridDim.x - 1) / gridDim.x;
         // A vector short enough to be parked whole is written in one burst at the very end, with
         // no meeting; a longer one in phases of kPhaseTiles tiles (measured on a 155-tile-per-CU
-        // vector: phases of 4..8 tiles 3.5 % faster than none, of 10..18 tiles 1-2.5 %: the
-        // blocks drift apart within a long phase and then wait for each other at its end).
+        // vector of 32 clients, kernel ms: no phases 3.79, phases of 1 / 2 / 3 / 4 / 5 / 6 / 8 /
+        // 12 / 16 tiles 4.17 / 3.73 / 3.60 / 3.56 / 3.59 / 3.60 / 3.62 / 3.68 / 3.69: shorter
+        // ones pay the drain-and-refill too often, in longer ones the blocks drift apart).
         if (a.phase_tiles > 0) {
             if (static_cast<unsigned>(a.phase_tiles) < P) P = static_cast<unsigned>(a.phase_tiles);
         } else if (most > P && P > kPhaseTiles) {
