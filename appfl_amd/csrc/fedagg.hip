@@ -1103,20 +1103,24 @@ int launch_reduce_u(const ReduceArgs& a, int unroll, hipStream_t st) {
 }
 
 // Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.  It
-// wins where one result vector per tile leaves room for long write bursts and the client list
-// is long (FedAvg from ~32 clients: +2-4 %, FedAvgM from ~48: +2 %).  The optimizers with two
-// moment vectors stay on the tile-per-block kernel: with four result vectors per tile the LDS
-// budget holds only three tiles per burst, and many resident waves hide their six state streams
-// better than one wave per SIMD (2-4 % faster at every K measured, 16..128).
+// wins where the client list is long: plain FedAvg from ~32 clients (+2-7 %), FedAvgM from ~48
+// (+2-4 %).  Under the two-moment optimizers four result vectors per tile leave LDS room for
+// phases of three tiles only, and many resident waves hide their six state streams better than
+// one wave per SIMD: there the persistent kernel needs 64 clients AND a long vector (measured
+// against the tile-per-block kernel: +4 % at 25 M elements x 64-96 clients, +8-11 % at 87-162 M
+// x 64, but -3 % at 12 M x 64 and -5...-10 % below 56 clients at every length).
 int stash_min_clients(int opt) {
     if (opt == FA_OPT_NONE) return 32;
     if (opt == FA_OPT_AVGM) return 48;
-    return FA_KCHUNK + 1;
+    return 64;
 }
+int stash_min_tiles_per_cu(int opt) { return opt >= FA_OPT_ADAM ? 20 : 1; }
 bool takes_stash_path(int opt, int K, uint64_t nvec) {
     if (g_shape.stash < 0) return K > kStashUnroll;
+    const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
     return g_shape.stash > 0 && K >= stash_min_clients(opt) &&
-           nvec >= static_cast<uint64_t>(device_cu_count()) * g_shape.stash * kStashTile;
+           nvec >= per_cu * static_cast<uint64_t>(g_shape.stash) &&
+           nvec >= per_cu * static_cast<uint64_t>(stash_min_tiles_per_cu(opt));
 }
 
 template <int OPT, int VEC>
