@@ -640,7 +640,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         if (!phased) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pipeline is empty, only stores are out
         if (a.sync & 1) grid_meet(meet);
-        issue_end += P;
+        if (issue_end != 0xFFFFFFFFu) issue_end += P;
     };
     issue(xa, full_a);
     issue(xb, full_b);
@@ -651,6 +651,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         consume(xb, full_b);
         end_phase();
         issue(xb, full_b);
+        // nothing in flight and nothing issued: cannot happen while tiles remain, but a wave
+        // must never spin here
+        if (!full_a && !full_b) break;
     }
     if (phased) grid_meet_leave(meet, meetings);
 }
