@@ -1106,15 +1106,15 @@ int launch_reduce_u(const ReduceArgs& a, int unroll, hipStream_t st) {
 }
 
 // Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.  It
-// wins where the client list is long: plain FedAvg from ~32 clients (+2-7 %), FedAvgM from ~48
-// (+2-4 %).  Under the two-moment optimizers four result vectors per tile leave LDS room for
+// wins where the client list is long: plain FedAvg from ~32 clients (+2-7 %; below, the
+// tile-per-block kernel is 3-18 % faster), FedAvgM from ~40 (+2-4 %).  Under the two-moment optimizers four result vectors per tile leave LDS room for
 // phases of three tiles only, and many resident waves hide their six state streams better than
 // one wave per SIMD: there the persistent kernel needs 64 clients AND a long vector (measured
 // against the tile-per-block kernel: +4 % at 25 M elements x 64-96 clients, +8-11 % at 87-162 M
 // x 64, but -3 % at 12 M x 64 and -5...-10 % below 56 clients at every length).
 int stash_min_clients(int opt) {
     if (opt == FA_OPT_NONE) return 32;
-    if (opt == FA_OPT_AVGM) return 48;
+    if (opt == FA_OPT_AVGM) return 40;
     return 64;
 }
 int stash_min_tiles_per_cu(int opt) { return opt >= FA_OPT_ADAM ? 20 : 1; }

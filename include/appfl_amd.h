@@ -73,7 +73,8 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * bit 4: the persistent kernel's blocks do not meet before their result bursts, bit 5: they
  * also meet after the bursts),
  * grid cap (<= 0: default) of the tile-per-block kernel, and from how many 16-KiB tiles per CU
- * on a launch with a long client list (FedAvg >= 32, FedAvgM >= 48 clients) takes the persistent
+ * on a launch with a long client list (FedAvg >= 32, FedAvgM >= 40, two-moment optimizers >= 64
+ * clients on long vectors) takes the persistent
  * kernel that parks results in LDS and writes them in bursts (stash: 0 never, < 0 always for
  * more than 8 clients, default 2).  Results do not depend on it.
  * Applies to launches made by the calling thread only (thread-local state).
