@@ -25,6 +25,14 @@ _d = C.c_double
 _f = C.c_float
 _u64 = C.c_uint64
 
+FA_DT_F32, FA_DT_I64, FA_DT_I32 = range(3)
+
+
+class MeanSegment(C.Structure):
+    """``fa_mean_segment``: one plain-mean segment of the client rows (fa_round)."""
+    _fields_ = [("row_offset", C.c_size_t), ("out", C.c_void_p), ("n", C.c_size_t),
+                ("dtype", C.c_int)]
+
 # name -> (restype, argtypes); mirrors include/appfl_amd.h one to one.
 SIGNATURES = {
     "fa_version": (_i, []),
@@ -33,6 +41,7 @@ SIGNATURES = {
     "fa_reduce_kernel_name": (C.c_char_p, [_i, _sz, _i]),
     "fa_tune": (_i, [_i, _i, _i, _i, _i]),
     "fa_reduce_opt": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),
+    "fa_round": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p, _i, _p]),
     "fa_reduce_apply": (_i, [_p, _p, _i, _p, _sz, _p, _p]),
     "fa_reduce_opt_static": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p]),
     "fa_reduce_opt_slab": (_i, [_p, _sz, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),

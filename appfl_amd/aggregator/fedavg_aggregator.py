@@ -333,11 +333,37 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self.step = {e.name: src[e.cls][e.offset:e.offset + e.numel].view(e.shape)
                          for e in lay.entries if e.cls in src}
 
+    # whether the plain-mean segments of a round may ride on the fused launch (subclasses whose
+    # `_launch_step` does something else than one fused call over the rows switch it off)
+    _fold_means = True
+
     def _launch_round(self, K: int, weights, fused: bool = True, events=None) -> None:
         """Enqueue one round's kernels over the K staged rows: the fused weighted-step /
         optimizer / apply kernel (or, un-fused, the apply of a step computed by compute_steps),
         then the plain means of the entries that bypass the step.  `events` = (start, end)
         torch.cuda.Event pair recorded around the fused kernel (benchmark timing)."""
+        lay = self._layout
+        if (fused and self._fold_means and lay.count[STEP] and not lay.count[STEP_F64]
+                and not lay.count[MEAN_F64] and hasattr(self._ops, "round_sync")):
+            # one call: the small plain-mean segments ride on the fused launch
+            n_step = lay.count[STEP]
+            self._ensure_moments()
+            ws = None
+            if K > self._ops.kchunk():
+                if self._step_flat is None:
+                    self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+                ws = self._step_flat
+            means = [(lay.seg_byte[cls], out, lay.count[cls])
+                     for cls, out in ((MEAN_F32, self._flats["f32"][n_step:]),
+                                      (MEAN_I64, self._flats["i64"]), (MEAN_I32, self._flats["i32"]))
+                     if lay.count[cls]]
+            if events:
+                events[0].record()
+            self._ops.round_sync(self._rows(K, 0), weights, self._flats["f32"], self._m, self._v,
+                                 self._OPT, step_ws=ws, n=n_step, means=means, **self._hyper())
+            if events:
+                events[1].record()
+            return
         self._launch_step(K, weights, fused, events)
         self._launch_means(K)
 

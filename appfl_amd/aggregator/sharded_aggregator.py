@@ -142,6 +142,8 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         return out
 
     # -- the round ----------------------------------------------------------------------------------
+    _fold_means = False   # the step runs block by block between collectives
+
     def _launch_step(self, K: int, weights, fused: bool = True, events=None) -> None:
         """Fused kernel on every local block, each followed by the all-gather of its block row.
         Every rank takes part in every gather, also one whose blocks are all empty."""

@@ -31,6 +31,20 @@ struct Hyper {
     float lr, b1, omb1, b2, omb2, tau;
 };
 
+// Plain-mean entries folded into a reduce launch (fa_round): up to three segments of the client
+// rows, addressed relative to x[k].  A few hundred to a few thousand elements (BatchNorm
+// statistics, counters): a launch of their own costs more than the work.
+constexpr int kTailSegments = 3;
+struct MeanTail {
+    void* out[kTailSegments];
+    long long off[kTailSegments];   // bytes from x[k] to the segment in client k's row
+    unsigned n[kTailSegments];
+    int dtype[kTailSegments];       // FA_DT_*
+    unsigned total;                 // elements over all segments (0: nothing folded)
+    unsigned blocks;                // tile-per-block kernel: leading blocks of the grid that do this work
+    float Kall;                     // client count as fp32
+};
+
 struct ReduceArgs {
     const float* x[FA_KCHUNK];
     float w[FA_KCHUNK];
@@ -49,8 +63,9 @@ struct ReduceArgs {
     int sync;   // persistent kernel, chip-wide write phases: bit 1 = the blocks meet before their
                 // result bursts, bit 0 = and again after the bursts have drained; 0 = no phases
     int phase_tiles;       // persistent kernel: tiles per phase (one burst); 0 = all the chip can park
-    unsigned* sync_word;   // zeroed counter the blocks of this launch meet on (sync != 0)
+    unsigned* sync_word;   // counter the blocks of this launch meet on (sync != 0); zero between launches
     Hyper h;
+    MeanTail mt;
 };
 
 template <int VEC>
@@ -155,6 +170,85 @@ __device__ __forceinline__ float optimizer_step(float step, float& m, float& v, 
     // -fhip-fp32-correctly-rounded-divide-sqrt); the __fsqrt_rn intrinsic is the 1-ulp v_sqrt_f32.
     float den = sqrtf(v) + h.tau;
     return num / den;
+}
+
+// Plain mean: the sum in client order, then torch.div by the client count (integers: fp32
+// true division, truncated back).
+__device__ __forceinline__ float mean_finish(float s, float kf) { return s / kf; }
+__device__ __forceinline__ int64_t mean_finish(int64_t s, float kf) {
+    return static_cast<int64_t>(static_cast<float>(s) / kf);
+}
+__device__ __forceinline__ int32_t mean_finish(int32_t s, float kf) {
+    return static_cast<int32_t>(static_cast<float>(s) / kf);
+}
+
+// Folded plain-mean entries.  A handful of elements (the usual case: num_batches_tracked
+// counters) go one per WAVE: lane k fetches client k's value, so one memory latency covers all
+// clients, and the values are then added in client order through lane reads.  More elements go
+// one per thread like mean_kernel, a few clients in flight at a time (a deeper batch would cost
+// the host kernels registers they need elsewhere).
+constexpr int kTailBatch = 8;
+constexpr unsigned kTailByWave = 64;   // up to this many elements: one wave each
+constexpr unsigned kWavesPerBlock = kThreads / 64;
+
+template <typename T>
+__device__ __forceinline__ const T* tail_src(const ReduceArgs& a, int k, long long off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.x[k]) + off);
+}
+
+template <typename T>
+__device__ __forceinline__ void mean_tail_element(const ReduceArgs& a, long long off, void* out, unsigned i) {
+    T s = static_cast<T>(0);
+    int k = 0;
+    for (; k + kTailBatch <= a.K; k += kTailBatch) {
+        T x[kTailBatch];
+#pragma unroll
+        for (int u = 0; u < kTailBatch; ++u) x[u] = __builtin_nontemporal_load(tail_src<T>(a, k + u, off) + i);
+#pragma unroll
+        for (int u = 0; u < kTailBatch; ++u) s = s + x[u];
+    }
+    for (; k < a.K; ++k) s = s + __builtin_nontemporal_load(tail_src<T>(a, k, off) + i);
+    static_cast<T*>(out)[i] = mean_finish(s, a.mt.Kall);
+}
+
+template <typename T>
+__device__ __forceinline__ void mean_tail_wave(const ReduceArgs& a, long long off, void* out, unsigned i) {
+    static_assert(FA_KCHUNK <= 128, "two values per lane cover a launch's clients");
+    const int lane = threadIdx.x & 63;
+    T x0 = static_cast<T>(0), x1 = static_cast<T>(0);
+    if (lane < a.K) x0 = __builtin_nontemporal_load(tail_src<T>(a, lane, off) + i);
+    if (lane + 64 < a.K) x1 = __builtin_nontemporal_load(tail_src<T>(a, lane + 64, off) + i);
+    T s = static_cast<T>(0);
+    for (int k = 0; k < a.K; ++k) s = s + __shfl(k < 64 ? x0 : x1, k & 63, 64);
+    if (lane == 0) static_cast<T*>(out)[i] = mean_finish(s, a.mt.Kall);
+}
+
+// `worker` = index of this block among the blocks that share the folded entries.
+__device__ __forceinline__ void mean_tail(const ReduceArgs& a, unsigned worker) {
+    const bool by_wave = a.mt.total <= kTailByWave;
+    unsigned e = by_wave ? worker * kWavesPerBlock + threadIdx.x / 64u : worker * kThreads + threadIdx.x;
+    if (e >= a.mt.total) return;
+#pragma unroll
+    for (int sgm = 0; sgm < kTailSegments; ++sgm) {
+        if (e < a.mt.n[sgm]) {
+            const long long off = a.mt.off[sgm];
+            void* out = a.mt.out[sgm];
+            if (a.mt.dtype[sgm] == FA_DT_F32) {
+                if (by_wave) mean_tail_wave<float>(a, off, out, e); else mean_tail_element<float>(a, off, out, e);
+            } else if (a.mt.dtype[sgm] == FA_DT_I64) {
+                if (by_wave) mean_tail_wave<int64_t>(a, off, out, e); else mean_tail_element<int64_t>(a, off, out, e);
+            } else {
+                if (by_wave) mean_tail_wave<int32_t>(a, off, out, e); else mean_tail_element<int32_t>(a, off, out, e);
+            }
+            return;
+        }
+        e -= a.mt.n[sgm];
+    }
+}
+
+// Blocks that share `total` folded elements.
+inline unsigned tail_blocks(unsigned total) {
+    return total <= kTailByWave ? (total + kWavesPerBlock - 1) / kWavesPerBlock : (total + kThreads - 1) / kThreads;
 }
 
 // Registers a thread holds for one tile (VPT vectors of VEC floats each).
@@ -278,7 +372,14 @@ __global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
     // two-moment optimizers at K = 32..64, +-1 % elsewhere); a ragged last window keeps the
     // plain order.
     constexpr unsigned R = (OPT >= FA_OPT_ADAM) ? 32u : 128u;
-    for (unsigned t0 = blockIdx.x; t0 < tiles; t0 += gridDim.x) {
+    // the first mt.blocks blocks of the grid take the folded plain-mean entries instead of tiles
+    const unsigned tb = a.mt.blocks;
+    if (blockIdx.x < tb) {
+        mean_tail(a, blockIdx.x);
+        return;
+    }
+    const unsigned nblocks = gridDim.x - tb;
+    for (unsigned t0 = blockIdx.x - tb; t0 < tiles; t0 += nblocks) {
         unsigned t = t0;
         const unsigned win = t0 & ~(8u * R - 1u);
         if (VEC == 4 && win + 8u * R <= tiles) t = win + (t0 & 7u) * R + ((t0 >> 3) & (R - 1u));
@@ -357,6 +458,13 @@ __device__ __forceinline__ void burst_store(float* base, unsigned bytes, unsigne
 // depend on it.
 constexpr unsigned kSyncPolls = 96;
 
+// Layout of a meeting counter: arrivals in the low bits, blocks that have left the kernel above
+// them.  The last block to leave puts the word back to zero, so a counter needs no clearing
+// between launches (a memset per launch costs more than a round of a small model's kernel).
+constexpr unsigned kLeaveShift = 20;
+constexpr unsigned kLeaveOne = 1u << kLeaveShift;
+constexpr unsigned kArriveMask = kLeaveOne - 1u;
+
 struct GridMeet {
     unsigned* word;
     unsigned arrivals;   // meetings this block has attended
@@ -375,7 +483,7 @@ __device__ __forceinline__ void grid_meet(GridMeet& m) {
             // vector 3.68 / 3.63 / 3.62 / 3.67, ResNet-50 K = 64 FedAvg 1.096 / 1.079 / 1.059 / 1.065).
             const unsigned target = m.arrivals * gridDim.x - gridDim.x / 2;
             unsigned polls = 0;
-            while (__hip_atomic_load(m.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            while ((__hip_atomic_load(m.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kArriveMask) < target) {
                 if (++polls >= kSyncPolls) {
                     m.gave_up = true;
                     break;
@@ -387,10 +495,18 @@ __device__ __forceinline__ void grid_meet(GridMeet& m) {
     __syncthreads();
 }
 
-// A block that leaves before the others still counts for the meetings it skips.
+// Every block of a phased launch calls this exactly once, as its last access to the counter.  A
+// block that leaves before the others still counts for the meetings it skips; the block that
+// finds all the others gone (their accesses to the word all precede their leave in the word's
+// modification order) zeroes it for the launch that gets this slot next.
 __device__ __forceinline__ void grid_meet_leave(GridMeet& m, unsigned expected) {
-    if (threadIdx.x == 0 && expected > m.arrivals)
-        __hip_atomic_fetch_add(m.word, expected - m.arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        const unsigned skipped = expected > m.arrivals ? expected - m.arrivals : 0u;
+        const unsigned old = __hip_atomic_fetch_add(m.word, kLeaveOne + skipped, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        if ((old >> kLeaveShift) == gridDim.x - 1u)
+            __hip_atomic_store(m.word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // The client loop of the persistent kernel is software-pipelined ACROSS tiles: two register
@@ -437,6 +553,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         // eighth one: a consistent +0.5 % (fewer rows open per XCD's slice of the fabric).
         unsigned slot = blockIdx.x;
         if (gridDim.x % 8 == 0) slot = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+        // folded plain-mean entries first, on the blocks with the highest slots: those are the
+        // ones with a tile less than the others when the tiles do not divide evenly
+        if (a.mt.total) mean_tail(a, gridDim.x - 1u - slot);
         // every block attends as many meetings as the busiest block
         const unsigned most = (total + gridDim.x - 1) / gridDim.x;
         // A vector short enough to be parked whole is written in one burst at the very end, with
@@ -452,7 +571,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         if (most <= P) phased = false;
         if (phased) meetings = ((most + P - 1) / P) * (((a.sync & 1) ? 1u : 0u) + ((a.sync & 2) ? 1u : 0u));
         if (slot >= total) {
-            grid_meet_leave(meet, meetings);
+            if (phased) grid_meet_leave(meet, meetings);
             return;
         }
         ntiles = (total - slot + gridDim.x - 1) / gridDim.x;
@@ -460,6 +579,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         r1 = a.n;
         tstride = gridDim.x * tlen;
     } else {
+        if (a.mt.total) mean_tail(a, gridDim.x - 1u - blockIdx.x);
         if (r0 >= r1) return;
         ntiles = (r1 - r0 + kStashTile - 1) / kStashTile;
     }
@@ -672,13 +792,6 @@ struct MeanArgs {
     float Kall;  // total client count as fp32
 };
 
-__device__ __forceinline__ float mean_finish(float s, float kf) { return s / kf; }
-__device__ __forceinline__ int64_t mean_finish(int64_t s, float kf) {
-    return static_cast<int64_t>(static_cast<float>(s) / kf);
-}
-__device__ __forceinline__ int32_t mean_finish(int32_t s, float kf) {
-    return static_cast<int32_t>(static_cast<float>(s) / kf);
-}
 
 // The client values of an element are loaded kMeanBatch at a time (independent loads in
 // flight) and then added in client order; with few elements the kernel is latency-bound, so the
@@ -1029,8 +1142,11 @@ int device_cu_count() {
 }  // namespace
 
 // Meeting counters of the persistent kernel's launches: kSyncSlots slots of one 256-byte line
-// each, handed out round-robin and zeroed on the launch's stream just before the launch.  (The
-// name is a host-side handle; the per-device address comes from hipGetSymbolAddress.)
+// each, handed out round-robin.  They start at zero (static storage) and every launch leaves
+// its counter at zero again (grid_meet_leave), so nothing is cleared between launches; a slot
+// comes round again after kSyncSlots launches, which are assumed not to be all in flight at
+// once.  (The name is a host-side handle; the per-device address comes from
+// hipGetSymbolAddress.)
 static __device__ __align__(256) unsigned sync_words[64 * 64];
 
 namespace {
@@ -1041,34 +1157,26 @@ std::mutex g_symbol_mutex;
 unsigned* g_sync_ptr[kMaxDevices] = {nullptr};
 unsigned g_sync_next[kMaxDevices] = {0};
 
-// A zeroed meeting counter for one launch on the current device (NULL: run without meetings).
-unsigned* next_sync_word(hipStream_t st) {
+// A meeting counter for one launch on the current device (NULL: run without meetings).
+unsigned* next_sync_word() {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    unsigned* word = nullptr;
-    {
-        std::lock_guard<std::mutex> hold(g_symbol_mutex);
-        if (!g_sync_ptr[dev]) {
-            unsigned* p = nullptr;
-            if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(sync_words)) != hipSuccess || !p) {
-                (void)hipGetLastError();
-                return nullptr;
-            }
-            g_sync_ptr[dev] = p;
+    std::lock_guard<std::mutex> hold(g_symbol_mutex);
+    if (!g_sync_ptr[dev]) {
+        unsigned* p = nullptr;
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(sync_words)) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return nullptr;
         }
-        word = g_sync_ptr[dev] + 64 * (g_sync_next[dev]++ % kSyncSlots);
+        g_sync_ptr[dev] = p;
     }
-    if (hipMemsetAsync(word, 0, 256, st) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    return word;
+    return g_sync_ptr[dev] + 64 * (g_sync_next[dev]++ % kSyncSlots);
 }
 
 template <int OPT, int MODE>
 int launch_stash_m(const ReduceArgs& a0, hipStream_t st) {
     ReduceArgs a = a0;
-    a.sync_word = (a.sync && a.il) ? next_sync_word(st) : nullptr;
+    a.sync_word = (a.sync && a.il) ? next_sync_word() : nullptr;
     hipLaunchKernelGGL((reduce_stash_kernel<OPT, MODE>), dim3(device_cu_count()), dim3(kThreads), 0, st, a);
     return launch_status();
 }
@@ -1085,7 +1193,7 @@ template <int OPT, int VEC, int VPT, int U, bool NT>
 int launch_reduce_s(const ReduceArgs& a, hipStream_t st) {
     size_t tiles = (static_cast<size_t>(a.n) + kThreads * VPT - 1) / (kThreads * VPT);
     size_t cap = static_cast<size_t>(g_shape.max_blocks > 0 ? g_shape.max_blocks : kMaxBlocks);
-    unsigned grid = static_cast<unsigned>(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
+    unsigned grid = static_cast<unsigned>(tiles < 1 ? 1 : (tiles > cap ? cap : tiles)) + a.mt.blocks;
     hipLaunchKernelGGL((reduce_kernel<OPT, VEC, VPT, U, NT>), dim3(grid), dim3(kThreads), 0, st, a);
     return launch_status();
 }
@@ -1177,6 +1285,8 @@ struct ReduceCall {
     float* step_out;
     float* step_ws;
     int apply;
+    const MeanTail* tail = nullptr;   // plain-mean entries to fold into the launch, if one can take them
+    bool* tail_done = nullptr;        // set when a launch took them
 };
 
 // Runs [off, off+len) of the flat axis: client chunks of FA_KCHUNK carry the partial step
@@ -1207,6 +1317,14 @@ int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStrea
         a.sync = g_sync;
         a.phase_tiles = g_phase_tiles;
         a.n = static_cast<unsigned>(vec ? len / 4 : len);
+        if (c.tail && c.tail_done && !*c.tail_done && chunks == 1) {
+            // the pointers of the tail are relative to x[k] of the whole vector
+            a.mt = *c.tail;
+            for (int sgm = 0; sgm < kTailSegments; ++sgm)
+                a.mt.off[sgm] -= static_cast<long long>(off * sizeof(float));
+            a.mt.blocks = tail_blocks(a.mt.total);
+            *c.tail_done = true;
+        }
         int rc = vec ? launch_reduce<4>(c.opt, a, st) : launch_reduce<1>(c.opt, a, st);
         if (rc != FA_OK) return rc;
     }
@@ -1466,6 +1584,64 @@ int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float
     ReduceCall c{x, w, K, g, nullptr, m, v, n, opt, make_hyper(lr, beta1, beta2, tau),
                  step_out, step_ws, 1};
     return reduce_dispatch(c, as_stream(stream));
+}
+
+int fa_round(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+             size_t n, int opt, double lr, double beta1, double beta2, double tau, float* step_out,
+             float* step_ws, const fa_mean_segment* means, int n_means, fa_stream_t stream) {
+    if (n_means < 0 || (n_means > 0 && !means) || !x || K <= 0) return FA_ERR_INVALID;
+    MeanTail tail;
+    memset(&tail, 0, sizeof(tail));
+    tail.Kall = static_cast<float>(K);
+    size_t total = 0;
+    bool foldable = n_means <= kTailSegments && K <= FA_KCHUNK && n > 0;
+    for (int i = 0; i < n_means; ++i) {
+        const fa_mean_segment& sg = means[i];
+        const size_t width = sg.dtype == FA_DT_I64 ? 8 : 4;
+        if (sg.dtype != FA_DT_F32 && sg.dtype != FA_DT_I64 && sg.dtype != FA_DT_I32) return FA_ERR_INVALID;
+        if (sg.n && !sg.out) return FA_ERR_INVALID;
+        if (!aligned_to(sg.out, width) || sg.row_offset % width) return FA_ERR_ALIGN;
+        for (int k = 0; k < K; ++k) {
+            if (!x[k]) return FA_ERR_INVALID;
+            if (!aligned_to(x[k], width)) return FA_ERR_ALIGN;
+        }
+        total += sg.n;
+        if (foldable) {
+            tail.out[i] = sg.out;
+            tail.off[i] = static_cast<long long>(sg.row_offset);
+            tail.n[i] = static_cast<unsigned>(sg.n);
+            tail.dtype[i] = sg.dtype;
+        }
+    }
+    // the folded entries ride on at most a quarter of the persistent kernel's blocks
+    foldable = foldable && total > 0 && total <= static_cast<size_t>(device_cu_count() / 4) * kThreads;
+    tail.total = foldable ? static_cast<unsigned>(total) : 0u;
+    bool done = false;
+    ReduceCall c{x, w, K, g, nullptr, m, v, n, opt, make_hyper(lr, beta1, beta2, tau),
+                 step_out, step_ws, 1};
+    if (foldable) {
+        c.tail = &tail;
+        c.tail_done = &done;
+    }
+    int rc = n > 0 ? reduce_dispatch(c, as_stream(stream)) : FA_OK;
+    if (rc != FA_OK || done) return rc;
+    for (int i = 0; i < n_means; ++i) {
+        const fa_mean_segment& sg = means[i];
+        std::vector<const void*> rows(static_cast<size_t>(K));
+        for (int k = 0; k < K; ++k)
+            rows[static_cast<size_t>(k)] = reinterpret_cast<const char*>(x[k]) + sg.row_offset;
+        if (sg.dtype == FA_DT_F32)
+            rc = mean_dispatch(reinterpret_cast<const float* const*>(rows.data()), K,
+                               static_cast<float*>(sg.out), sg.n, as_stream(stream));
+        else if (sg.dtype == FA_DT_I64)
+            rc = mean_dispatch(reinterpret_cast<const int64_t* const*>(rows.data()), K,
+                               static_cast<int64_t*>(sg.out), sg.n, as_stream(stream));
+        else
+            rc = mean_dispatch(reinterpret_cast<const int32_t* const*>(rows.data()), K,
+                               static_cast<int32_t*>(sg.out), sg.n, as_stream(stream));
+        if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
 }
 
 int fa_reduce_apply(const float* const* x, const double* w, int K, float* g, size_t n,

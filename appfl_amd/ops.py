@@ -92,6 +92,37 @@ def reduce_opt(x: Sequence[torch.Tensor], w: Sequence[float], g: torch.Tensor,
     N.check(rc, "fa_reduce_opt")
 
 
+_MEAN_DT = {torch.float32: N.FA_DT_F32, torch.int64: N.FA_DT_I64, torch.int32: N.FA_DT_I32}
+
+
+def round_sync(x: Sequence, w: Sequence[float], g: torch.Tensor,
+               m: Optional[torch.Tensor] = None, v: Optional[torch.Tensor] = None,
+               opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
+               tau: float = 0.0, step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None,
+               means: Sequence = ()) -> None:
+    """One synchronous round over K client rows in as few launches as possible (fa_round):
+    `reduce_opt` over ``g[:n]`` plus the plain mean of every ``(row_offset_bytes, out, count)``
+    in `means` -- segments found `row_offset_bytes` after ``x[k]`` in every client's row, whose
+    means go to ``out[:count]`` (f32 / i64 / i32 by `out`'s dtype)."""
+    n = g.numel() if n is None else n
+    if len(x) != len(w):
+        raise ValueError("one weight per client buffer")
+    for t in (m, v, step_ws):
+        if t is not None and t.numel() < n:
+            raise ValueError("state / workspace tensor shorter than n")
+    segs = (N.MeanSegment * max(len(means), 1))()
+    for i, (off, out, count) in enumerate(means):
+        if out.numel() < count:
+            raise ValueError("mean output shorter than its segment")
+        segs[i] = N.MeanSegment(int(off), _dev(out), int(count), _MEAN_DT[out.dtype])
+    rc = N.load().fa_round(_check_rows(x, n, torch.float32), N.double_array([float(t) for t in w]),
+                           len(x), _dev(g, torch.float32), _dev(m, torch.float32),
+                           _dev(v, torch.float32), n, OPT_CODES[opt], float(lr), float(beta1),
+                           float(beta2), float(tau), None, _dev(step_ws, torch.float32),
+                           segs, len(means), _stream(g))
+    N.check(rc, "fa_round")
+
+
 def reduce_opt_slab(slab: torch.Tensor, stride: int, w: Sequence[float], g: torch.Tensor,
                     m=None, v=None, opt: str = "none", lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
                     step_out=None, step_ws=None, n: Optional[int] = None) -> None:

@@ -8,8 +8,8 @@
  * returns.  Calls on one stream execute in order.  The library is thread-compatible
  * (concurrent calls must use different buffers); the only device state it owns are two
  * static arrays per GPU: 16 KiB of meeting counters its persistent reduce kernel uses for
- * timing only (a slot per launch, zeroed on the launch's stream; results never depend on
- * them) and the workspace of fa_reduce_opt_static.
+ * timing only (a slot per launch, which the launch itself leaves at zero again; results never
+ * depend on them) and the workspace of fa_reduce_opt_static.
  *
  * Arithmetic contract: each documented formula is evaluated as separately rounded IEEE fp32
  * operations in the written order (no FMA contraction, correctly rounded / and sqrt, denormals
@@ -104,6 +104,32 @@ int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);
 int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float* m, float* v,
                   size_t n, int opt, double lr, double beta1, double beta2, double tau,
                   float* step_out, float* step_ws, fa_stream_t stream);
+
+/*
+ * One whole synchronous round over K client ROWS of one layout: fa_reduce_opt over the weighted
+ * fp32 entries (x[k] = start of client k's weighted segment, n floats) plus the plain mean --
+ * fa_mean_f32 / fa_mean_i64 / fa_mean_i32 below -- of every segment listed in `means`, found
+ * `row_offset` bytes after x[k] in every client's row.  Replaces the whole loop body of
+ * FedAvgAggregator.aggregate (algorithm/aggregator/fedavg_aggregator.py:273-296: step-path
+ * entries at :276-283, bypassing entries at :285-296).  Results are those of the separate
+ * calls, bit for bit; the point is the launch count: small segments (BatchNorm statistics,
+ * num_batches_tracked counters) ride on spare blocks of the reduce launch instead of taking
+ * launches of their own, which for small and mid-size models cost more than the work.  The
+ * library folds them when K <= FA_KCHUNK, n_means <= 3 and they are few enough elements
+ * (some thousands); otherwise it enqueues the separate mean kernels itself.
+ * means: HOST array of n_means descriptors (may be NULL when n_means == 0); out: device buffer
+ * of n elements of `dtype`.
+ */
+enum { FA_DT_F32 = 0, FA_DT_I64 = 1, FA_DT_I32 = 2 };
+typedef struct fa_mean_segment {
+    size_t row_offset; /* bytes from x[k] to this segment in client k's row */
+    void* out;         /* device: receives the n means                       */
+    size_t n;          /* elements                                           */
+    int dtype;         /* FA_DT_*                                            */
+} fa_mean_segment;
+int fa_round(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+             size_t n, int opt, double lr, double beta1, double beta2, double tau, float* step_out,
+             float* step_ws, const fa_mean_segment* means, int n_means, fa_stream_t stream);
 
 /*
  * fa_reduce_opt for callers that cannot allocate device memory (code under HIP graph capture,

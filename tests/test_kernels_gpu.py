@@ -354,3 +354,85 @@ def test_weighted_mix(mode, code, n, K):
     ws = torch.empty_like(g) if K > ops.kchunk() else None
     ops.weighted_mix([dev(x) for x in xs], w, g, mode, coeff, acc_ws=ws)
     assert_bits(g, g_ref, "g")
+
+
+def _round_rows(n_step, counts, K, seed):
+    """K client rows [step f32 | mean f32 | pad16 | i64 | i32] as numpy pieces and as one device
+    slab; returns (base, per-client pieces, slab, row stride in bytes, byte offsets)."""
+    n_f32, n_i64, n_i32 = counts
+    rng = np.random.default_rng(seed)
+    base, xs = make_clients(n_step, K, seed=seed, spike=n_step > 16)
+    off_f32 = 4 * n_step
+    off_i64 = (off_f32 + 4 * n_f32 + 15) // 16 * 16
+    off_i32 = off_i64 + 8 * n_i64
+    stride = (off_i32 + 4 * n_i32 + 255) // 256 * 256
+    pieces = []
+    slab = np.zeros((K, stride), np.uint8)
+    for k in range(K):
+        f = O.synth_fill(max(n_f32, 1), 50 + k, scale=1.0)[:n_f32]
+        a = rng.integers(-2 ** 40, 2 ** 40, n_i64).astype(np.int64)
+        b = rng.integers(-10 ** 6, 10 ** 6, n_i32).astype(np.int32)
+        if n_i64 >= 3:
+            a[:3] = [6, 7, -7] if k == 0 else 0
+        pieces.append((xs[k], f, a, b))
+        slab[k, :off_f32] = xs[k].view(np.uint8)
+        slab[k, off_f32:off_f32 + 4 * n_f32] = f.view(np.uint8)
+        slab[k, off_i64:off_i64 + 8 * n_i64] = a.view(np.uint8)
+        slab[k, off_i32:off_i32 + 4 * n_i32] = b.view(np.uint8)
+    return base, pieces, torch.from_numpy(slab).cuda(), stride, (off_f32, off_i64, off_i32)
+
+
+@pytest.mark.parametrize("opt,hp", [("none", {}), ("adam", HP)])
+@pytest.mark.parametrize("n_step,K,counts", [
+    (4099, 3, (5, 3, 2)),            # one wave per element
+    (4099, 100, (0, 20, 0)),         # the usual case: a few counters, many clients
+    (1027, 128, (7, 0, 1)),
+    (300007, 10, (300, 20, 9)),      # one thread per element, on leading blocks of the grid
+    (300007, 70, (3000, 0, 0)),
+    (2500003, 40, (0, 20, 0)),       # persistent kernel, by wave
+    (2500003, 100, (9000, 53, 5)),   # persistent kernel, by thread
+    (2500003, 33, (20000, 3, 0)),    # too many elements to fold: separate mean launches
+    (4099, 130, (5, 3, 2)),          # more clients than one launch folds: separate launches
+    (3, 5, (2, 1, 1)),               # no 128-bit body: the scalar kernel carries the tail
+    (0, 4, (5, 3, 2)),               # no weighted entries at all
+])
+def test_round_folds_plain_means_into_the_reduce_launch(opt, hp, n_step, K, counts):
+    from appfl_amd import ops
+    if n_step == 0 and opt != "none":
+        pytest.skip("nothing to optimise")
+    code = {"none": O.OPT_NONE, "adam": O.OPT_ADAM}[opt]
+    base, pieces, slab, stride, offs = _round_rows(n_step, counts, K, seed=11)
+    w = [(3 + 2 * k) / sum(3 + 2 * j for j in range(K)) for k in range(K)]
+    g_ref = base.copy()
+    m_ref = np.zeros_like(base)
+    v_ref = np.full_like(base, np.float32(HP["tau"] ** 2))
+    if n_step:
+        O.reduce_opt([p[0] for p in pieces], w, g_ref, m_ref, v_ref, code, **hp)
+    wants = []
+    for j, dt in enumerate((np.float32, np.int64, np.int32)):
+        want = np.zeros(counts[j], dt)
+        if counts[j]:
+            O.mean([p[1 + j] for p in pieces], want)
+        wants.append(want)
+    g = dev(base) if n_step else torch.zeros(4, device="cuda")
+    m = torch.zeros_like(g)
+    v = torch.full_like(g, HP["tau"] ** 2)
+    outs = [torch.full((max(c, 1),), -77, dtype=t, device="cuda")
+            for c, t in zip(counts, (torch.float32, torch.int64, torch.int32))]
+    rows = [slab.data_ptr() + k * stride for k in range(K)]
+    ws = torch.empty(max(n_step, 1), device="cuda") if K > ops.kchunk() else None
+    means = [(offs[j], outs[j], counts[j]) for j in range(3) if counts[j]]
+    for _ in range(2):       # twice: the second round starts from the first one's state (same client rows)
+        ops.round_sync(rows, w, g, m if opt != "none" else None, v if opt != "none" else None,
+                       opt, step_ws=ws, n=n_step, means=means, **hp)
+        if _ == 0 and n_step:
+            O.reduce_opt([p[0] for p in pieces], w, g_ref, m_ref, v_ref, code, **hp)
+    torch.cuda.synchronize()
+    if n_step:
+        assert_bits(g[:n_step], g_ref, "g")
+        if opt != "none":
+            assert_bits(m, m_ref, "m")
+            assert_bits(v, v_ref, "v")
+    for j, name in enumerate(("mean f32", "mean i64", "mean i32")):
+        if counts[j]:
+            assert_bits(outs[j][:counts[j]], wants[j], name)
