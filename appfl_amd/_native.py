@@ -67,6 +67,7 @@ SIGNATURES = {
     "fa_server_opt_step_f64": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _p]),
     "fa_apply_step_f64": (_i, [_p, _p, _sz, _p]),
     "fa_mean_f64": (_i, [_p, _i, _p, _sz, _p]),
+    "fa_weighted_mix_f64": (_i, [_p, _p, _i, _p, _d, _i, _p, _sz, _p]),
     "fa_async_mix_f64": (_i, [_p, _d, _i, _i, _p, _p, _sz, _p]),
     "fa_buff_accum_f64": (_i, [_p, _d, _i, _p, _p, _i, _sz, _p]),
     "fa_buff_accum_flush_f64": (_i, [_p, _d, _i, _p, _p, _i, _sz, _p]),

@@ -21,7 +21,7 @@ from typing import Any, Dict, Optional, OrderedDict, Union
 import torch
 
 from .. import ops
-from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout
+from ..layout import MEAN_F32, MEAN_F64, MEAN_I32, MEAN_I64, STEP, STEP_F64, Layout
 from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import BaseAggregator, DeviceStateMixin, cfg_get, resolve_device
 from .staleness import fedasync_staleness, fedqueue_staleness
@@ -43,6 +43,7 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
         self._flats: Optional[Dict[str, torch.Tensor]] = None
         self._slab: Optional[ClientSlab] = None
         self._acc_ws: Optional[torch.Tensor] = None
+        self._acc_ws64: Optional[torch.Tensor] = None
         self._dl = HostDownloader()
         self._init_lock()
 
@@ -64,7 +65,8 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
     def _download(self) -> Dict[str, torch.Tensor]:
         lay = self._layout
         host = {}
-        for key, n in (("f32", lay.n_f32), ("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
+        for key, n in (("f32", lay.n_f32), ("f64", lay.n_f64), ("i64", lay.count[MEAN_I64]),
+                       ("i32", lay.count[MEAN_I32])):
             host[key] = self._dl.fetch(self._flats[key], n)
         return lay.views(host)
 
@@ -78,10 +80,6 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
             init = dict(first_model)
         self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
                               self.named_parameters)
-        if self._layout.n_f64:
-            raise NotImplementedError(
-                "float64 entries are supported by the FedAvg family, FedAsync and FedBuff; the "
-                "FedCompass / FedQueue mixes take fp32 and integer entries")
         self._flats = self._layout.alloc_state(self.device)
         with torch.no_grad():
             for n, t in init.items():
@@ -105,30 +103,38 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
         return [self._slab.row_ptr(k) + byte_offset for k in range(K)]
 
     def _mix(self, K: int, weights, mode: str, coeff: float = 0.0) -> None:
-        n = self._layout.count[STEP]
-        if not n:
-            return
-        ws = None
-        if K > ops.kchunk() and mode != "subtract":
-            if self._acc_ws is None:
-                self._acc_ws = torch.empty(n, dtype=torch.float32, device=self.device)
-            ws = self._acc_ws
-        ops.weighted_mix(self._rows(K, 0), weights, self._flats["f32"], mode, coeff, acc_ws=ws, n=n)
+        """The weighted entries: fp32 and float64 segments take the same mix (for float64 tensors
+        PyTorch keeps the Python scalars in double, and so does the f64 kernel)."""
+        lay = self._layout
+        for cls, key, dtype, ws_attr in ((STEP, "f32", torch.float32, "_acc_ws"),
+                                         (STEP_F64, "f64", torch.float64, "_acc_ws64")):
+            n = lay.count[cls]
+            if not n:
+                continue
+            ws = None
+            if K > ops.kchunk() and mode != "subtract":
+                if getattr(self, ws_attr) is None:
+                    setattr(self, ws_attr, torch.empty(n, dtype=dtype, device=self.device))
+                ws = getattr(self, ws_attr)
+            ops.weighted_mix(self._rows(K, lay.seg_byte[cls]), weights, self._flats[key], mode, coeff,
+                             acc_ws=ws, n=n)
+
+    def _non_step_segments(self):
+        """(class, flat key, dtype, offset in the flat vector) of the entries that bypass the mix."""
+        lay = self._layout
+        return ((MEAN_F32, "f32", torch.float32, lay.count[STEP]),
+                (MEAN_F64, "f64", torch.float64, lay.count[STEP_F64]),
+                (MEAN_I64, "i64", torch.int64, 0), (MEAN_I32, "i32", torch.int32, 0))
 
     def _plain_means(self, K: int) -> None:
-        lay, n_step = self._layout, self._layout.count[STEP]
-        if lay.count[MEAN_F32]:
-            ops.mean(self._rows(K, lay.seg_byte[MEAN_F32]), self._flats["f32"][n_step:],
-                     n=lay.count[MEAN_F32])
-        if lay.count[MEAN_I64]:
-            ops.mean(self._rows(K, lay.seg_byte[MEAN_I64]), self._flats["i64"], n=lay.count[MEAN_I64])
-        if lay.count[MEAN_I32]:
-            ops.mean(self._rows(K, lay.seg_byte[MEAN_I32]), self._flats["i32"], n=lay.count[MEAN_I32])
+        lay = self._layout
+        for cls, key, _, lo in self._non_step_segments():
+            if lay.count[cls]:
+                ops.mean(self._rows(K, lay.seg_byte[cls]), self._flats[key][lo:], n=lay.count[cls])
 
     def _replace_non_step(self) -> None:
-        lay, n_step = self._layout, self._layout.count[STEP]
-        for cls, key, dtype, lo in ((MEAN_F32, "f32", torch.float32, n_step),
-                                    (MEAN_I64, "i64", torch.int64, 0), (MEAN_I32, "i32", torch.int32, 0)):
+        lay = self._layout
+        for cls, key, dtype, lo in self._non_step_segments():
             cnt = lay.count[cls]
             if cnt:
                 self._flats[key][lo:lo + cnt].copy_(self._slab.row_view(0, lay.seg_byte[cls], cnt, dtype))

@@ -196,6 +196,59 @@ __global__ __launch_bounds__(kThreads) void flush_mean64_kernel(double* g, const
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) g[i] = step[i] / kf;
 }
 
+// Weighted mixes of K client vectors that do not subtract g first (FedCompass / FedQueue):
+// the six combine modes of the fp32 mix_kernel, in double.
+struct Mix64Args {
+    const double* x[FA_KCHUNK];
+    double w[FA_KCHUNK];
+    double* g;
+    const double* acc_in;   // partial sum of earlier client chunks (NULL: 0)
+    double* acc_out;        // where a non-final chunk leaves its partial sum
+    size_t n;
+    int K, mode, last;
+    double coeff;
+};
+
+__global__ __launch_bounds__(kThreads) void mix64_kernel(const Mix64Args a) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.n; i += stride) {
+        double g = 0.0;
+        if (a.mode != FA_MIX_REPLACE && a.mode != FA_MIX_SUM_SET) g = a.g[i];
+        double acc;
+        if (a.mode == FA_MIX_SUBTRACT)
+            acc = g;
+        else if (a.acc_in)
+            acc = a.acc_in[i];
+        else
+            acc = (a.mode >= FA_MIX_CONVEX_ONE) ? -0.0 : 0.0;   // -0 + y == y for every y
+        int k = 0;
+        for (; k + kAhead <= a.K; k += kAhead) {
+            double x[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) x[u] = __builtin_nontemporal_load(a.x[k + u] + i);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                double xw = x[u] * a.w[k + u];
+                acc = (a.mode == FA_MIX_SUBTRACT) ? acc - xw : acc + xw;
+            }
+        }
+        for (; k < a.K; ++k) {
+            double xw = __builtin_nontemporal_load(a.x[k] + i) * a.w[k];
+            acc = (a.mode == FA_MIX_SUBTRACT) ? acc - xw : acc + xw;
+        }
+        if (!a.last && a.mode != FA_MIX_SUBTRACT) {
+            a.acc_out[i] = acc;
+            continue;
+        }
+        if ((a.mode == FA_MIX_CONVEX || a.mode == FA_MIX_CONVEX_ONE) && a.last) {
+            double gt = g * a.coeff;
+            acc = gt + acc;
+        }
+        if (a.mode == FA_MIX_SUM_ADD && a.last) acc = g + acc;
+        a.g[i] = acc;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void fill64_kernel(double* p, double value, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) p[i] = value;
@@ -348,6 +401,42 @@ int fa_mean_f64(const double* const* x, int K, double* g, size_t n, fa_stream_t 
         a.last = (ch == chunks - 1);
         a.Kall = static_cast<double>(K);
         hipLaunchKernelGGL(mean64_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(stream), a);
+        int rc = launch_status();
+        if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
+}
+
+int fa_weighted_mix_f64(const double* const* x, const double* w, int K, double* g, double coeff,
+                        int mode, double* acc_ws, size_t n, fa_stream_t stream) {
+    if (!x || !w || !g || K <= 0) return FA_ERR_INVALID;
+    if (mode < FA_MIX_REPLACE || mode > FA_MIX_SUM_SET) return FA_ERR_INVALID;
+    if (mode == FA_MIX_CONVEX_ONE && K != 1) return FA_ERR_INVALID;
+    if (K > FA_KCHUNK && mode != FA_MIX_SUBTRACT && !acc_ws) return FA_ERR_WORKSPACE;
+    if (!aligned8(g) || (acc_ws && !aligned8(acc_ws))) return FA_ERR_ALIGN;
+    for (int k = 0; k < K; ++k) {
+        if (!x[k]) return FA_ERR_INVALID;
+        if (!aligned8(x[k])) return FA_ERR_ALIGN;
+    }
+    if (n == 0) return FA_OK;
+    const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
+    for (int ch = 0; ch < chunks; ++ch) {
+        Mix64Args a;
+        memset(&a, 0, sizeof(a));
+        const int k0 = ch * FA_KCHUNK;
+        a.K = (K - k0 < FA_KCHUNK) ? K - k0 : FA_KCHUNK;
+        for (int k = 0; k < a.K; ++k) {
+            a.x[k] = x[k0 + k];
+            a.w[k] = w[k0 + k];
+        }
+        a.g = g;
+        a.acc_in = (ch == 0 || mode == FA_MIX_SUBTRACT) ? nullptr : acc_ws;
+        a.acc_out = acc_ws;
+        a.n = n;
+        a.mode = mode;
+        a.last = (ch == chunks - 1);
+        a.coeff = coeff;
+        hipLaunchKernelGGL(mix64_kernel, dim3(grid_for(n)), dim3(kThreads), 0, as_stream(stream), a);
         int rc = launch_status();
         if (rc != FA_OK) return rc;
     }

@@ -180,10 +180,9 @@ def weighted_mix(x: Sequence, w: Sequence[float], g: torch.Tensor, mode: str, co
     n = g.numel() if n is None else n
     if len(x) != len(w):
         raise ValueError("one weight per client buffer")
-    rc = N.load().fa_weighted_mix(_check_rows(x, n, torch.float32),
-                                  N.double_array([float(t) for t in w]), len(x),
-                                  _dev(g, torch.float32), float(coeff), MIX_MODES[mode],
-                                  _dev(acc_ws, torch.float32), n, _stream(g))
+    fn, dt = _float_entry("fa_weighted_mix", g)
+    rc = fn(_check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x), _dev(g, dt),
+            float(coeff), MIX_MODES[mode], _dev(acc_ws, dt), n, _stream(g))
     N.check(rc, "fa_weighted_mix")
 
 

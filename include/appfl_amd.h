@@ -266,6 +266,8 @@ int fa_server_opt_step_f64(double* step, double* m, double* v, size_t n, int opt
                            double beta2, double tau, fa_stream_t stream);
 int fa_apply_step_f64(double* g, const double* step, size_t n, fa_stream_t stream);
 int fa_mean_f64(const double* const* x, int K, double* g, size_t n, fa_stream_t stream);
+int fa_weighted_mix_f64(const double* const* x, const double* w, int K, double* g, double coeff,
+                        int mode, double* acc_ws, size_t n, fa_stream_t stream);
 int fa_async_mix_f64(const double* x, double alpha_t, int gradient_based, int sub_form, double* g,
                      double* step_out, size_t n, fa_stream_t stream);
 int fa_buff_accum_f64(const double* x, double alpha_t, int gradient_based, const double* g, double* step,

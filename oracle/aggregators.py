@@ -535,10 +535,10 @@ class OracleFedCompass(_OracleMixBase):
                 if not self._is_step_name(name):
                     self.global_state[name] = local_model[name].copy()          # :166
                 elif gb:
-                    self.global_state[name] = self.global_state[name] - local_model[name] * _f32(alpha_t)
+                    self.global_state[name] = self.global_state[name] - local_model[name] * _sc(alpha_t, local_model[name])
                 else:                                                           # :177-181
-                    self.global_state[name] = self.global_state[name] * _f32(1 - alpha_t) \
-                        + local_model[name] * _f32(alpha_t)
+                    self.global_state[name] = self.global_state[name] * _sc(1 - alpha_t, self.global_state[name]) \
+                        + local_model[name] * _sc(alpha_t, local_model[name])
             return self._finish()
         local_models = {c: {k: to_np(v) for k, v in m.items()} for c, m in local_models.items()}
         if self.global_state is None:
@@ -552,14 +552,14 @@ class OracleFedCompass(_OracleMixBase):
                 if not self._is_step_name(name):
                     continue
                 if gb:
-                    self.global_state[name] = self.global_state[name] - local_models[cid][name] * _f32(alpha_t)
+                    self.global_state[name] = self.global_state[name] - local_models[cid][name] * _sc(alpha_t, local_models[cid][name])
                 else:
-                    acc[name] = acc[name] + local_models[cid][name] * _f32(alpha_t)
+                    acc[name] = acc[name] + local_models[cid][name] * _sc(alpha_t, local_models[cid][name])
         for name in list(self.global_state):
             if not self._is_step_name(name):
                 self.global_state[name] = self._plain_mean(name, local_models)
             elif not gb:
-                self.global_state[name] = self.global_state[name] * _f32(1 - alpha_t_sum) + acc[name]
+                self.global_state[name] = self.global_state[name] * _sc(1 - alpha_t_sum, self.global_state[name]) + acc[name]
         return self._finish()
 
 
@@ -605,9 +605,9 @@ class OracleFedQueue(_OracleMixBase):
                 if not self._is_step_name(name):
                     continue
                 if gb:
-                    self.global_state[name] = self.global_state[name] - m[name] * _f32(f[cid])
+                    self.global_state[name] = self.global_state[name] - m[name] * _sc(f[cid], m[name])
                 else:
-                    acc[name] = acc[name] + m[name] * _f32(f[cid])
+                    acc[name] = acc[name] + m[name] * _sc(f[cid], m[name])
         for name in list(self.global_state):
             if not self._is_step_name(name):
                 self.global_state[name] = self._plain_mean(name, local_models)

@@ -386,6 +386,16 @@ def float64_scenarios() -> List[Dict]:
         out.append({"id": f"{cls[:-10]}-f64-{'model' if with_model else 'nomodel'}-{'grad' if gb else 'model'}",
                     "kind": "async", "cls": cls, "spec": "mixed64", "model": with_model, "cfg": cfg,
                     "script": ASYNC_SCRIPT[:6], "sample_sizes": {}})
+    for gb, with_model in ((False, False), (True, True)):
+        out.append({"id": f"FedCompass-f64-{'grad' if gb else 'model'}-{'model' if with_model else 'nomodel'}",
+                    "kind": "compass", "cls": "FedCompassAggregator", "spec": "mixed64", "model": with_model,
+                    "cfg": dict(STALENESS["polynomial"], alpha=0.9, num_clients=3, gradient_based=gb),
+                    "sample_sizes": {}})
+        out.append({"id": f"FedQueue-f64-{'grad' if gb else 'model'}-{'model' if with_model else 'nomodel'}",
+                    "kind": "queue", "cls": "FedQueueAggregator", "spec": "mixed64", "model": with_model,
+                    "cfg": {"staleness_fn": "harmonic", "staleness_fn_kwargs": {"beta": 0.5},
+                            "gradient_based": gb},
+                    "sample_sizes": {0: 12, 1: 30, 2: 7}})
     out.append({"id": "FedAvg-f64-chunked", "kind": "chunked", "cls": "FedAvgAggregator", "spec": "mixed64",
                 "model": False, "cfg": dict(HP["FedAvgAggregator"], client_weights_mode="equal"),
                 "rounds": [2, 3], "chunk_bytes": 400, "whole_after": [2], "sample_sizes": {}})

@@ -356,6 +356,47 @@ def test_weighted_mix(mode, code, n, K):
     assert_bits(g, g_ref, "g")
 
 
+@pytest.mark.parametrize("mode", ["replace", "convex", "subtract", "convex_one", "sum_add", "sum_set"])
+@pytest.mark.parametrize("n,K", [(5, 1), (4099, 3), (2051, 131)])
+def test_weighted_mix_float64(mode, n, K):
+    """The f64 mixes against the same op sequence in numpy doubles (each numpy op is one
+    correctly rounded IEEE operation); values and weights are not representable in fp32."""
+    from appfl_amd import ops
+    if mode == "convex_one":
+        K = 1
+    rng = np.random.default_rng(n + K)
+    base = rng.standard_normal(n) * 0.05
+    xs = [base + rng.standard_normal(n) * 0.01 for _ in range(K)]
+    if n > 16:
+        xs[0][3] = 0.0
+        xs[K - 1][5] = 1e300
+        xs[0][7] = -0.0
+        xs[0][11] = 1e-310          # denormal
+    w = [0.9 * (k + 1) ** -0.5 / 7 for k in range(K)]
+    coeff = 1 - sum(w)
+    want = base.copy()
+    if mode == "subtract":
+        for x, wk in zip(xs, w):
+            want = want - x * np.float64(wk)
+    else:
+        acc = xs[0] * np.float64(w[0]) if mode in ("convex_one", "sum_add", "sum_set") \
+            else np.zeros(n) + xs[0] * np.float64(w[0])
+        for x, wk in zip(xs[1:], w[1:]):
+            acc = acc + x * np.float64(wk)
+        if mode in ("convex", "convex_one"):
+            want = base * np.float64(coeff) + acc
+        elif mode == "sum_add":
+            want = base + acc
+        else:
+            want = acc
+    g = dev(base)
+    ws = torch.empty_like(g) if K > ops.kchunk() else None
+    ops.weighted_mix([dev(x) for x in xs], w, g, mode, coeff, acc_ws=ws)
+    got = g.cpu().numpy()
+    bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+    assert bad.size == 0, f"{bad.size} of {n} differ, first at {bad[:5]}: {got[bad[:5]]} vs {want[bad[:5]]}"
+
+
 def _round_rows(n_step, counts, K, seed):
     """K client rows [step f32 | mean f32 | pad16 | i64 | i32] as numpy pieces and as one device
     slab; returns (base, per-client pieces, slab, row stride in bytes, byte offsets)."""
