@@ -9,8 +9,9 @@ packer copies just those windows of every client tensor into the pinned slot, th
 1/R as long, the fused kernel runs on the local blocks with no collective in the arithmetic, and
 the RCCL all-gathers of the block rows -- pipelined behind the kernels -- leave the whole new
 model on every rank, which downloads it like the single-GPU class.  Integer / non-parameter
-entries (a few KB) are averaged redundantly on every rank.  Results are bit-identical to the
-single-GPU aggregators.
+entries (a few KB) are averaged redundantly on every rank, and so are float64 entries (rare and
+small: they stay whole, with moments of their own, on every rank).  Results are bit-identical to
+the single-GPU aggregators.
 
 Collectives happen in `aggregate` only.  `get_parameters` is local: it serves the model every
 rank holds after the last gather (or the initial state), so one rank may answer client requests
@@ -28,7 +29,7 @@ from typing import Any, Dict, Optional
 import torch
 import torch.distributed as dist
 
-from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, Layout, WindowedLayout
+from ..layout import MEAN_F32, MEAN_I32, MEAN_I64, STEP, STEP_F64, Layout, WindowedLayout
 from ..sharded import ShardMap, round_gather_pipelined
 from ..staging import ClientSlab
 from .base_aggregator import cfg_require
@@ -75,9 +76,16 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         z = dict(dtype=torch.float32, device=self.device)
         if self._OPT != "none" and self._v is None:
             self._v = torch.zeros(L, **z)
+            n64 = self._layout.count[STEP_F64]
+            if n64:
+                self._v64 = torch.zeros(n64, dtype=torch.float64, device=self.device)
             if self._OPT != "avgm":       # fedadam_aggregator.py:41-50: m = 0, v = tau**2
+                tau = cfg_require(self.aggregator_configs, "server_adapt_param")
                 self._m = torch.zeros(L, **z)
-                self._ops.fill(self._v, cfg_require(self.aggregator_configs, "server_adapt_param") ** 2)
+                self._ops.fill(self._v, tau ** 2)
+                if n64:
+                    self._m64 = torch.zeros(n64, dtype=torch.float64, device=self.device)
+                    self._ops.fill(self._v64, tau ** 2)
 
     # -- state ------------------------------------------------------------------------------------
     def _names_layout(self) -> Layout:
@@ -122,9 +130,10 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         f32 = self._gathered[:n_step]
         if full.count[MEAN_F32]:
             f32 = torch.cat([f32, self._flats["f32"][L:L + full.count[MEAN_F32]]])
-        return {"f32": f32, "i64": self._flats["i64"], "i32": self._flats["i32"]}
+        return {"f32": f32, "f64": self._flats["f64"], "i64": self._flats["i64"],
+                "i32": self._flats["i32"]}
 
-    def _moment_views(self, flat):
+    def _moment_views(self, flat, flat64=None):
         """The moments live sharded (`_m` / `_v` hold this rank's blocks); no per-name views."""
         return {}
 
@@ -134,6 +143,7 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         n_step, n_mean = full.count[STEP], full.count[MEAN_F32]
         host = {"f32": self._dl.fetch_parts([self._gathered[:n_step],
                                              self._flats["f32"][L:L + n_mean]]),
+                "f64": self._dl.fetch(self._flats["f64"], full.n_f64),
                 "i64": self._dl.fetch(self._flats["i64"], full.count[MEAN_I64]),
                 "i32": self._dl.fetch(self._flats["i32"], full.count[MEAN_I32])}
         out = full.views(host)
@@ -157,6 +167,16 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         round_gather_pipelined(self._ops, smap, self._rows(K, 0) if smap.n_local else [], weights,
                                self._flats["f32"], self._m, self._v, self._OPT, self._hyper(),
                                self._gathered, self.group, ws)
+        n64 = self._layout.count[STEP_F64]
+        if n64:      # whole on every rank
+            ws64 = None
+            if K > self._ops.kchunk():
+                if self._step_flat64 is None:
+                    self._step_flat64 = torch.empty(n64, dtype=torch.float64, device=self.device)
+                ws64 = self._step_flat64
+            self._ops.reduce_opt(self._rows(K, self._layout.seg_byte[STEP_F64]), weights,
+                                 self._flats["f64"], self._m64, self._v64, self._OPT, step_ws=ws64,
+                                 n=n64, **self._hyper())
 
     @_native
     def compute_steps(self, local_models):

@@ -161,14 +161,13 @@ class WindowedLayout(Layout):
     and state vectors keep the shape of :class:`Layout` -- ``[step storage | mean fp32 | ints]``
     -- so the staging slab and the kernels work on them unchanged; `entries` holds one PIECE per
     (step entry, window) intersection, so a name may appear more than once, and the plain-mean
-    entries whole (they are kept on every rank).  Name-based views belong to the full layout.
+    and float64 entries whole (they are kept on every rank).  Name-based views belong to the
+    full layout.
     """
 
     def __init__(self, full: Layout, windows: Sequence[Tuple[int, int, int]], storage: int):
         if storage % 4:
             raise ValueError("step storage must be a multiple of 4 elements (16 bytes)")
-        if full.n_f64:
-            raise NotImplementedError("float64 entries are not sharded; use the single-GPU aggregators")
         self.full = full
         self.count = dict(full.count)
         self.count[STEP] = storage
@@ -176,7 +175,7 @@ class WindowedLayout(Layout):
         if self.live_step > storage:
             raise ValueError("windows exceed the step storage")
         self.n_f32 = storage + full.count[MEAN_F32]
-        self.n_f64 = 0
+        self.n_f64 = full.n_f64          # float64 entries (rare, small) stay whole on every rank
         self._place_segments()
         self.entries = []
         for e in full.entries:

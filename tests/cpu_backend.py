@@ -20,7 +20,7 @@ def _np(t, n=None):
     return a if n is None else a[:n]
 
 
-_CT = {np.float32: C.c_float, np.int64: C.c_int64, np.int32: C.c_int32}
+_CT = {np.float32: C.c_float, np.float64: C.c_double, np.int64: C.c_int64, np.int32: C.c_int32}
 
 
 def _rows(x, n, dtype=np.float32):
@@ -39,12 +39,38 @@ def kchunk():
 
 
 def fill(p, value, n=None):
-    _np(p, n)[...] = np.float32(value)
+    a = _np(p, n)
+    a[...] = a.dtype.type(value)
+
+
+def _reduce_opt64(xs, w, g, m, v, opt, lr, beta1, beta2, tau):
+    """float64 entries: the op sequence of oracle/aggregators.py in numpy doubles (scalars stay
+    double, as PyTorch keeps them for float64 tensors)."""
+    s = np.zeros_like(g)
+    for x, wk in zip(xs, w):
+        s = s + (x - g) * np.float64(wk)
+    if opt == "avgm":
+        v[...] = v * beta1 + s
+        s = v.copy()
+    elif opt != "none":
+        m[...] = m * beta1 + s * (1 - beta1)
+        s2 = s * s
+        if opt == "adam":
+            v[...] = v * beta2 + s2 * (1 - beta2)
+        elif opt == "yogi":
+            v[...] = v - (s2 * np.sign(v - s2)) * (1 - beta2)
+        else:
+            v[...] = v + s2
+        s = (lr * m) / (np.sqrt(v) + tau)
+    g[...] = g + s
 
 
 def reduce_opt(x, w, g, m=None, v=None, opt="none", lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
                step_out=None, step_ws=None, n=None):
     n = g.numel() if n is None else n
+    if g.dtype == torch.float64:
+        return _reduce_opt64(_rows(x, n, np.float64), w, _np(g, n), _np(m, n), _np(v, n), opt, lr,
+                             beta1, beta2, tau)
     OC.reduce_opt(_rows(x, n), w, _np(g, n), _np(m, n), _np(v, n),
                   _CODE[opt], lr=lr, beta1=beta1, beta2=beta2, tau=tau, step_out=_np(step_out, n))
 
@@ -67,4 +93,11 @@ def apply_step(g, step, n=None):
 
 def mean(x, g, n=None):
     n = g.numel() if n is None else n
-    OC.mean(_rows(x, n, _np(g, n).dtype.type), _np(g, n))
+    out = _np(g, n)
+    if out.dtype == np.float64:
+        acc = np.zeros_like(out)
+        for a in _rows(x, n, np.float64):
+            acc = acc + a
+        out[...] = acc / np.float64(len(x))
+        return
+    OC.mean(_rows(x, n, out.dtype.type), out)

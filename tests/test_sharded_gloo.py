@@ -214,3 +214,41 @@ def test_three_ranks_on_a_five_element_model_one_rank_empty(tmp_path):
         want = ora.aggregate({c: S.make_state(TINY, seed=40 * r + c) for c in range(3)})
         for k in want:
             assert got[r][k].tobytes() == want[k].tobytes(), (r, k)
+
+
+def _f64_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        cfg = dict(S.HP["FedYogiAggregator"], client_weights_mode="equal")
+        agg = ShardedFedAvgAggregator(S.Mixed64Model(), cfg, None, algorithm="FedYogi", device="cpu",
+                                      backend=cpu_backend, pieces=2)
+        recs = []
+        for r, K in enumerate([3, 2]):
+            local = {c: S.make_state(S.MIXED64, seed=900 + 10 * r + c) for c in range(K)}
+            recs.append({k: v.numpy().copy() for k, v in agg.aggregate(local).items()})
+        if rank == 1:
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_with_float64_entries_kept_whole_on_every_rank(tmp_path):
+    """float64 parameters and buffers beside the sharded fp32 ones: every rank steps them whole,
+    with moments of its own; bit-identical to the single-process oracle."""
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_f64_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out, allow_pickle=True)
+    cfg = dict(S.HP["FedYogiAggregator"], client_weights_mode="equal")
+    ora = OA.OracleFedYogi(S.Mixed64Model(), cfg, None)
+    for r, K in enumerate([3, 2]):
+        want = ora.aggregate({c: S.make_state(S.MIXED64, seed=900 + 10 * r + c) for c in range(K)})
+        assert list(got[r]) == list(want)
+        for k in want:
+            w = want[k].numpy() if isinstance(want[k], torch.Tensor) else want[k]
+            assert got[r][k].dtype == w.dtype and got[r][k].tobytes() == w.tobytes(), (r, k)

@@ -39,14 +39,16 @@ def test_single_rank_modes_match_oracle(mode, pieces):
     assert np.array_equal(got[:n].view(np.uint32), g.view(np.uint32)) and not got[n:].any()
 
 
-def test_state_dict_sharded_aggregator_single_rank_matches_plain_aggregator_and_oracle():
+@pytest.mark.parametrize("spec_name", ["toy", "mixed64"])
+def test_state_dict_sharded_aggregator_single_rank_matches_plain_aggregator_and_oracle(spec_name):
     import scenarios as S
     import appfl_amd.aggregator as A
     from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+    spec, model = (S.TOY, S.ToyModel) if spec_name == "toy" else (S.MIXED64, S.Mixed64Model)
     cfg = dict(S.HP["FedYogiAggregator"], client_weights_mode="sample_size")
-    plain = A.FedYogiAggregator(S.ToyModel(), cfg, None)
-    shard = ShardedFedAvgAggregator(S.ToyModel(), cfg, None, algorithm="FedYogi", pieces=3)
-    ora = OA.OracleFedYogi(S.ToyModel(), cfg, None)
+    plain = A.FedYogiAggregator(model(), cfg, None)
+    shard = ShardedFedAvgAggregator(model(), cfg, None, algorithm="FedYogi", pieces=3)
+    ora = OA.OracleFedYogi(model(), cfg, None)
     for agg in (plain, shard, ora):
         for c in range(4):
             agg.set_client_sample_size(c, 5 + 2 * c)
@@ -54,7 +56,7 @@ def test_state_dict_sharded_aggregator_single_rank_matches_plain_aggregator_and_
     for k, t in ora.get_parameters().items():
         assert golden_util.same_bits(first[k].numpy(), np.asarray(t)), k
     for r, K in enumerate([3, 4, 2]):
-        local = {c: S.make_state(S.TOY, seed=900 + 10 * r + c) for c in range(K)}
+        local = {c: S.make_state(spec, seed=900 + 10 * r + c) for c in range(K)}
         want = plain.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
         truth = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
         if r == 1:
@@ -69,7 +71,8 @@ def test_state_dict_sharded_aggregator_single_rank_matches_plain_aggregator_and_
     for k in got:
         assert golden_util.same_bits(again[k].numpy(), got[k].numpy()), k
     gs = shard.global_state
-    assert golden_util.same_bits(gs["fc.weight"].cpu().numpy(), got["fc.weight"].numpy())
+    for k in got:
+        assert golden_util.same_bits(gs[k].cpu().numpy(), got[k].numpy()), k
 
 
 def _two_rank_worker(rank, world, port, out):
