@@ -41,7 +41,7 @@ SIGNATURES = {
     "fa_reduce_kernel_name": (C.c_char_p, [_i, _sz, _i]),
     "fa_tune": (_i, [_i, _i, _i, _i, _i]),
     "fa_reduce_opt": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),
-    "fa_round": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p, _i, _p]),
+    "fa_round": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p, _i, _i, _p, _p]),
     "fa_reduce_apply": (_i, [_p, _p, _i, _p, _sz, _p, _p]),
     "fa_reduce_opt_static": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p]),
     "fa_reduce_opt_slab": (_i, [_p, _sz, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),

@@ -80,8 +80,10 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         lay = self._layout
         host = {}
         for key, n in lay.flat_sizes().items():
-            host[key] = self._dl.fetch(self._flats[key], n)
-        return lay.views(host)
+            host[key] = self._dl.fetch(self._flats[key], n, wait=False)
+        out = lay.views(host)          # while the transfers are in flight
+        self._dl.wait(self.device)
+        return out
 
     def _init_global_state(self, local_model):
         """fedasync_aggregator.py:110-149: the model's entries when it has every name the client
@@ -220,10 +222,11 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         if lay.n_f32 > n_step:
             out_f32[n_step:].copy_(g[n_step:lay.n_f32], non_blocking=True)
         for key, n in (("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
-            host[key] = self._dl.fetch(self._flats[key], n)
+            host[key] = self._dl.fetch(self._flats[key], n, wait=False)
+        out = lay.views(host)          # while the last transfers are in flight
         compute.synchronize()
         self._down_stream.synchronize()
-        return lay.views(host)
+        return out
 
     # -- aggregate: fedasync_aggregator.py:103-184 ------------------------------------------------
     def aggregate(self, client_id: Union[str, int], local_model: Union[Dict, OrderedDict],

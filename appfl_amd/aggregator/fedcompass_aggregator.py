@@ -67,8 +67,10 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
         host = {}
         for key, n in (("f32", lay.n_f32), ("f64", lay.n_f64), ("i64", lay.count[MEAN_I64]),
                        ("i32", lay.count[MEAN_I32])):
-            host[key] = self._dl.fetch(self._flats[key], n)
-        return lay.views(host)
+            host[key] = self._dl.fetch(self._flats[key], n, wait=False)
+        out = lay.views(host)          # while the transfers are in flight
+        self._dl.wait(self.device)
+        return out
 
     def _init_global_state(self, first_model):
         """The model's entries for the names the first client sent, else the client's tensors

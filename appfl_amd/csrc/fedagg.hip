@@ -1287,18 +1287,33 @@ struct ReduceCall {
     int apply;
     const MeanTail* tail = nullptr;   // plain-mean entries to fold into the launch, if one can take them
     bool* tail_done = nullptr;        // set when a launch took them
+    int k_ready = 0;                  // 0 < k_ready < K: only the first k_ready clients' rows have landed;
+    hipEvent_t rest_event = nullptr;  // ... the launches that read the others wait for this event
 };
 
-// Runs [off, off+len) of the flat axis: client chunks of FA_KCHUNK carry the partial step
-// through `carry` (step_out when given, else step_ws).
+// Where the launches of one call cut the client list: every FA_KCHUNK clients, and at
+// `k_ready` when the caller says that only the first k_ready clients' rows have landed yet.
+int next_cut(const ReduceCall& c, int k0) {
+    int k1 = (c.K - k0 < FA_KCHUNK) ? c.K : k0 + FA_KCHUNK;
+    if (k0 < c.k_ready && c.k_ready < k1) k1 = c.k_ready;
+    return k1;
+}
+
+// Runs [off, off+len) of the flat axis: the client chunks carry the partial step through
+// `carry` (step_out when given, else step_ws).
 int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStream_t st) {
-    const int chunks = (c.K + FA_KCHUNK - 1) / FA_KCHUNK;
     float* carry = c.step_out ? c.step_out : c.step_ws;
-    for (int ch = 0; ch < chunks; ++ch) {
+    for (int k0 = 0; k0 < c.K;) {
+        const int k1 = next_cut(c, k0);
+        if (k0 > 0 && k0 == c.k_ready && c.rest_event) {
+            // the remaining clients' rows are still on their way: everything launched so far
+            // overlaps their transfer, what follows waits for it
+            hipError_t e = hipStreamWaitEvent(st, c.rest_event, 0);
+            if (e != hipSuccess) return hip_code(e);
+        }
         ReduceArgs a;
         memset(&a, 0, sizeof(a));
-        const int k0 = ch * FA_KCHUNK;
-        a.K = (c.K - k0 < FA_KCHUNK) ? c.K - k0 : FA_KCHUNK;
+        a.K = k1 - k0;
         for (int k = 0; k < a.K; ++k) {
             a.x[k] = c.x[k0 + k] + off;
             a.w[k] = static_cast<float>(c.w[k0 + k]);
@@ -1307,9 +1322,9 @@ int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStrea
         a.g_ro = c.g_ro ? c.g_ro + off : nullptr;
         a.m = c.m ? c.m + off : nullptr;
         a.v = c.v ? c.v + off : nullptr;
-        a.last = (ch == chunks - 1);
+        a.last = (k1 == c.K);
         a.apply = c.apply;
-        a.step_in = (ch == 0) ? nullptr : carry + off;
+        a.step_in = (k0 == 0) ? nullptr : carry + off;
         a.step_out = a.last ? (c.step_out ? c.step_out + off : nullptr) : carry + off;
         a.h = c.h;
         a.wt = g_write_through;
@@ -1317,7 +1332,7 @@ int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStrea
         a.sync = g_sync;
         a.phase_tiles = g_phase_tiles;
         a.n = static_cast<unsigned>(vec ? len / 4 : len);
-        if (c.tail && c.tail_done && !*c.tail_done && chunks == 1) {
+        if (c.tail && c.tail_done && !*c.tail_done && k0 == 0 && k1 == c.K) {
             // the pointers of the tail are relative to x[k] of the whole vector
             a.mt = *c.tail;
             for (int sgm = 0; sgm < kTailSegments; ++sgm)
@@ -1327,6 +1342,7 @@ int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStrea
         }
         int rc = vec ? launch_reduce<4>(c.opt, a, st) : launch_reduce<1>(c.opt, a, st);
         if (rc != FA_OK) return rc;
+        k0 = k1;
     }
     return FA_OK;
 }
@@ -1337,7 +1353,7 @@ int reduce_dispatch(const ReduceCall& c, hipStream_t st) {
     if (c.opt < FA_OPT_NONE || c.opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
     if (c.opt != FA_OPT_NONE && !c.v) return FA_ERR_INVALID;
     if (c.opt >= FA_OPT_ADAM && !c.m) return FA_ERR_INVALID;
-    if (c.K > FA_KCHUNK && !c.step_out && !c.step_ws) return FA_ERR_WORKSPACE;
+    if (next_cut(c, 0) < c.K && !c.step_out && !c.step_ws) return FA_ERR_WORKSPACE;
     if (c.n == 0) return FA_OK;
     const void* gp = c.apply ? static_cast<const void*>(c.g) : static_cast<const void*>(c.g_ro);
     bool a4 = aligned_to(gp, 4), a16 = aligned16(gp);
@@ -1588,13 +1604,16 @@ int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float
 
 int fa_round(const float* const* x, const double* w, int K, float* g, float* m, float* v,
              size_t n, int opt, double lr, double beta1, double beta2, double tau, float* step_out,
-             float* step_ws, const fa_mean_segment* means, int n_means, fa_stream_t stream) {
+             float* step_ws, const fa_mean_segment* means, int n_means, int k_ready,
+             void* rest_event, fa_stream_t stream) {
     if (n_means < 0 || (n_means > 0 && !means) || !x || K <= 0) return FA_ERR_INVALID;
+    if (k_ready < 0 || k_ready > K) return FA_ERR_INVALID;
+    const bool split = k_ready > 0 && k_ready < K;
     MeanTail tail;
     memset(&tail, 0, sizeof(tail));
     tail.Kall = static_cast<float>(K);
     size_t total = 0;
-    bool foldable = n_means <= kTailSegments && K <= FA_KCHUNK && n > 0;
+    bool foldable = n_means <= kTailSegments && K <= FA_KCHUNK && n > 0 && !split;
     for (int i = 0; i < n_means; ++i) {
         const fa_mean_segment& sg = means[i];
         const size_t width = sg.dtype == FA_DT_I64 ? 8 : 4;
@@ -1623,8 +1642,17 @@ int fa_round(const float* const* x, const double* w, int K, float* g, float* m, 
         c.tail = &tail;
         c.tail_done = &done;
     }
+    if (split) {
+        c.k_ready = k_ready;
+        c.rest_event = static_cast<hipEvent_t>(rest_event);
+    }
     int rc = n > 0 ? reduce_dispatch(c, as_stream(stream)) : FA_OK;
     if (rc != FA_OK || done) return rc;
+    if (split && n == 0 && rest_event) {
+        // no weighted entries, so nothing has waited yet: the means below read every client's row
+        hipError_t e = hipStreamWaitEvent(as_stream(stream), static_cast<hipEvent_t>(rest_event), 0);
+        if (e != hipSuccess) return hip_code(e);
+    }
     for (int i = 0; i < n_means; ++i) {
         const fa_mean_segment& sg = means[i];
         std::vector<const void*> rows(static_cast<size_t>(K));

@@ -99,11 +99,14 @@ def round_sync(x: Sequence, w: Sequence[float], g: torch.Tensor,
                m: Optional[torch.Tensor] = None, v: Optional[torch.Tensor] = None,
                opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
                tau: float = 0.0, step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None,
-               means: Sequence = ()) -> None:
+               means: Sequence = (), k_ready: int = 0,
+               rest_event: Optional["torch.cuda.Event"] = None) -> None:
     """One synchronous round over K client rows in as few launches as possible (fa_round):
     `reduce_opt` over ``g[:n]`` plus the plain mean of every ``(row_offset_bytes, out, count)``
     in `means` -- segments found `row_offset_bytes` after ``x[k]`` in every client's row, whose
-    means go to ``out[:count]`` (f32 / i64 / i32 by `out`'s dtype)."""
+    means go to ``out[:count]`` (f32 / i64 / i32 by `out`'s dtype).  `k_ready` / `rest_event`:
+    only the first `k_ready` clients' rows have landed; they are folded at once, the rest after
+    `rest_event` (recorded behind the remaining transfers) -- needs `step_ws`."""
     n = g.numel() if n is None else n
     if len(x) != len(w):
         raise ValueError("one weight per client buffer")
@@ -119,7 +122,9 @@ def round_sync(x: Sequence, w: Sequence[float], g: torch.Tensor,
                            len(x), _dev(g, torch.float32), _dev(m, torch.float32),
                            _dev(v, torch.float32), n, OPT_CODES[opt], float(lr), float(beta1),
                            float(beta2), float(tau), None, _dev(step_ws, torch.float32),
-                           segs, len(means), _stream(g))
+                           segs, len(means), int(k_ready),
+                           C.c_void_p(rest_event.cuda_event) if rest_event is not None else None,
+                           _stream(g))
     N.check(rc, "fa_round")
 
 

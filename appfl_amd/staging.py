@@ -42,6 +42,7 @@ class ClientSlab:
         self.slot_free = [None] * slots   # event recorded after the slot's last H2D copy
         self.next_slot = 0
         self.last_copy: Optional[torch.cuda.Event] = None
+        self.row_event: Dict[int, "torch.cuda.Event"] = {}   # row -> event after its last upload
         self.has_device_sources = False   # the last upload read device tensors of the caller
 
     def reserve(self, rows: int, preserve: int = 0) -> None:
@@ -177,6 +178,8 @@ class ClientSlab:
             ev = self._copy_event()
         self.slot_free[slot] = ev
         self.last_copy = ev
+        if ev is not None:
+            self.row_event[k] = ev
         self.has_device_sources = bool(dev_items)
         del keep
 
@@ -185,6 +188,17 @@ class ClientSlab:
         device tensors may overwrite them once this returns)."""
         if self.last_copy is not None:
             self.last_copy.synchronize()
+
+    def ready_prefix(self, rows) -> int:
+        """How many leading rows of `rows` (row indices in client order) have landed already.
+        A kernel launched now may read those; the others are behind `last_copy`."""
+        n = 0
+        for r in rows:
+            ev = self.row_event.get(r)
+            if ev is not None and not ev.query():
+                break
+            n += 1
+        return n
 
     def end_round(self) -> None:
         """Make the compute stream wait for every upload of this round."""
@@ -250,7 +264,10 @@ class HostDownloader:
         self._pinned: Dict[torch.dtype, torch.Tensor] = {}
         self._pool = pool if pool is not None else _PinnedPool()
 
-    def fetch(self, flat: torch.Tensor, n: int) -> torch.Tensor:
+    def fetch(self, flat: torch.Tensor, n: int, wait: bool = True) -> torch.Tensor:
+        """`wait=False` only enqueues the transfer: the caller does host work meanwhile (building
+        the per-entry views of the result takes a quarter of the transfer's time for a ResNet)
+        and must call :meth:`wait` for `flat`'s device before reading the tensor."""
         if n == 0:
             return torch.empty(0, dtype=flat.dtype)
         if not flat.is_cuda:           # CPU rehearsal of the sharded aggregator: already host memory
@@ -261,9 +278,16 @@ class HostDownloader:
             out = torch.frombuffer(lease, dtype=flat.dtype, count=n)
             del lease
             out.copy_(flat[:n], non_blocking=True)
-            torch.cuda.current_stream(flat.device).synchronize()
+            if wait:
+                self.wait(flat.device)
             return out
         return self._fetch_pageable(flat, n)
+
+    @staticmethod
+    def wait(device) -> None:
+        """Blocks until the transfers enqueued by `fetch(..., wait=False)` have landed."""
+        if torch.device(device).type == "cuda":
+            torch.cuda.current_stream(device).synchronize()
 
     def fetch_parts(self, parts: List[torch.Tensor]) -> torch.Tensor:
         """One fresh host tensor holding the concatenation of `parts` (1-D device tensors of one

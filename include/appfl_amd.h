@@ -119,6 +119,14 @@ int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float
  * (some thousands); otherwise it enqueues the separate mean kernels itself.
  * means: HOST array of n_means descriptors (may be NULL when n_means == 0); out: device buffer
  * of n elements of `dtype`.
+ * k_ready / rest_event: for a caller that is still uploading the last clients' rows when it
+ * starts the round.  With 0 < k_ready < K the rows of clients 0..k_ready-1 must be complete;
+ * the library folds them at once in a launch of their own (the partial step travels through
+ * step_ws, which is then required: same client order, same bits, as for K > FA_KCHUNK), makes
+ * `stream` wait for rest_event (a hipEvent_t recorded after the remaining rows' transfers;
+ * NULL: the caller has ordered them before `stream` itself) and only then folds the rest and
+ * takes the means -- so the bulk of the round overlaps the last transfers.  k_ready = 0 or K:
+ * one fused launch, rest_event ignored.
  */
 enum { FA_DT_F32 = 0, FA_DT_I64 = 1, FA_DT_I32 = 2 };
 typedef struct fa_mean_segment {
@@ -129,7 +137,8 @@ typedef struct fa_mean_segment {
 } fa_mean_segment;
 int fa_round(const float* const* x, const double* w, int K, float* g, float* m, float* v,
              size_t n, int opt, double lr, double beta1, double beta2, double tau, float* step_out,
-             float* step_ws, const fa_mean_segment* means, int n_means, fa_stream_t stream);
+             float* step_ws, const fa_mean_segment* means, int n_means, int k_ready,
+             void* rest_event, fa_stream_t stream);
 
 /*
  * fa_reduce_opt for callers that cannot allocate device memory (code under HIP graph capture,

@@ -213,6 +213,39 @@ def test_staging_on_arrival_gives_the_same_round():
             assert torch.equal(got[k], want[k]), (r, k)
 
 
+@pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedAdamAggregator"])
+@pytest.mark.parametrize("landed", ["all_but_last", "half", "one"])
+def test_round_starts_on_the_rows_that_have_landed(cls, landed, monkeypatch):
+    """aggregate() folds the clients whose uploads have landed while the last rows still travel
+    (two launches, the partial step carried through a workspace).  Which rows have landed is a
+    matter of timing, so the test dictates it; the bits must be the oracle's either way."""
+    import appfl_amd.aggregator as A
+    from appfl_amd.staging import ClientSlab
+    seen = []
+
+    def ready_prefix(self, rows):
+        K = len(list(rows))
+        k = {"all_but_last": K - 1, "half": (K + 1) // 2, "one": 1}[landed]
+        seen.append((K, k))
+        return k
+
+    monkeypatch.setattr(ClientSlab, "ready_prefix", ready_prefix)
+    cfg = dict(S.HP[cls], client_weights_mode="sample_size")
+    agg, ora = getattr(A, cls)(S.ToyModel(), cfg, None), OA.ORACLES[cls](S.ToyModel(), cfg, None)
+    for a in (agg, ora):
+        for c in range(6):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    for r, K in enumerate([4, 6, 2]):
+        models = {c: S.make_state(S.TOY, seed=300 + 10 * r + c) for c in range(K)}
+        truth = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        for c in list(models)[: K - 1]:
+            agg.stage(c, models[c])
+        got = agg.aggregate(models)
+        for k in truth:
+            assert golden_util.same_bits(got[k].numpy(), truth[k]), (r, k)
+    assert len(seen) == 3
+
+
 def test_stage_bytes_reads_the_wire_buffer_in_place():
     """Updates handed over as torch.save bytes (what the communicators receive) give the same
     round as deserialised state dicts."""

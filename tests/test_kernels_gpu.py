@@ -477,3 +477,54 @@ def test_round_folds_plain_means_into_the_reduce_launch(opt, hp, n_step, K, coun
     for j, name in enumerate(("mean f32", "mean i64", "mean i32")):
         if counts[j]:
             assert_bits(outs[j][:counts[j]], wants[j], name)
+
+
+@pytest.mark.parametrize("opt,hp", [("none", {}), ("yogi", HP_YOGI)])
+@pytest.mark.parametrize("n_step,K,k_ready", [
+    (4099, 3, 2), (4099, 100, 99), (4099, 100, 50), (1027, 128, 1), (300007, 70, 69),
+    (2500003, 40, 39),               # the first launch takes the persistent kernel
+    (4099, 200, 199), (4099, 200, 60), (4099, 200, 128),   # beside the cuts every FA_KCHUNK clients
+])
+def test_round_split_where_the_uploads_have_landed(opt, hp, n_step, K, k_ready):
+    """fa_round with k_ready: the landed clients in one launch, the rest after the event; the
+    partial step travels through the workspace, so the bits are those of one launch."""
+    from appfl_amd import ops
+    code = {"none": O.OPT_NONE, "yogi": O.OPT_YOGI}[opt]
+    counts = (5, 3, 2)
+    base, pieces, slab, stride, offs = _round_rows(n_step, counts, K, seed=23)
+    w = [(3 + 2 * k) / sum(3 + 2 * j for j in range(K)) for k in range(K)]
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v_ref = np.full_like(base, np.float32(HP["tau"] ** 2))
+    O.reduce_opt([p[0] for p in pieces], w, g_ref, m_ref, v_ref, code, **hp)
+    wants = []
+    for j, dt in enumerate((np.float32, np.int64, np.int32)):
+        want = np.zeros(counts[j], dt)
+        O.mean([p[1 + j] for p in pieces], want)
+        wants.append(want)
+    g = dev(base)
+    m, v = torch.zeros_like(g), torch.full_like(g, HP["tau"] ** 2)
+    outs = [torch.full((c,), -77, dtype=t, device="cuda")
+            for c, t in zip(counts, (torch.float32, torch.int64, torch.int32))]
+    rows = [slab.data_ptr() + k * stride for k in range(K)]
+    means = [(offs[j], outs[j], counts[j]) for j in range(3)]
+    ws = torch.empty(n_step, device="cuda")
+    with pytest.raises(Exception):       # a split needs the workspace
+        ops.round_sync(rows[:100], w[:100], g, n=n_step, k_ready=min(k_ready, 99))
+    # the remaining rows "arrive" on a side stream: the event is recorded behind a copy that
+    # rewrites them in place
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        tail = slab[k_ready:].clone()
+        slab[k_ready:].copy_(tail)
+        landed = torch.cuda.Event()
+        landed.record(side)
+    ops.round_sync(rows, w, g, m if opt != "none" else None, v if opt != "none" else None, opt,
+                   step_ws=ws, n=n_step, means=means, k_ready=k_ready, rest_event=landed, **hp)
+    torch.cuda.synchronize()
+    assert_bits(g, g_ref, "g")
+    if opt != "none":
+        assert_bits(m, m_ref, "m")
+        assert_bits(v, v_ref, "v")
+    for j, name in enumerate(("mean f32", "mean i64", "mean i32")):
+        assert_bits(outs[j], wants[j], name)
