@@ -18,7 +18,9 @@ K = 32 FedAvg round (or of --workload's flat vector): the parameter axis is deal
 blocks (appfl_amd.sharded.ShardMap), every rank aggregates its blocks of every client update and
 RCCL all-gathers hand every rank the whole new model.  `value` times the product path
 (`round_sliced_gather`: kernels and gathers pipelined over the block rows); "no_collective",
-"allgather" (round, then gather) and "allgather_pipelined" report the three forms side by side.
+"allgather" (round, then gather) and "allgather_pipelined" report the three forms side by side;
+"workloads" holds the same three forms for the ResNet-50 K = 64 FedAdam / FedYogi rounds
+(BASELINE configuration 3, which is quoted on 1/2/4/8 GPUs) dealt to the same ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -43,6 +45,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (datasheet)
 DEFAULT_WORKLOAD = "resnet18_fedavg_k100"
 SHARDED_WORKLOAD = "flat1300m_fedavg_k32"
 NORTH_STAR_WORKLOAD = "resnet50_fedadam_k64"
+SHARDED_EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64"]
 EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "flat162m_fedavg_k32",
                    "vitb16_fedasync", "vitb16_fedbuff_k16"]
 _OPT_OF = {"FedAvgAggregator": "none", "FedAvgMAggregator": "avgm", "FedAdamAggregator": "adam",
@@ -418,6 +421,34 @@ def measure_workload(name, steps, warmup, barrier):
     return out
 
 
+def measure_sharded(name, wl, world, rank, steps, warmup, barrier, use_dist):
+    """One FedAvg-family workload dealt to the ranks: the three timed forms (every rank runs this,
+    the gathers are collectives), the local kernel's roofline entry and the shard geometry."""
+    b = ShardedBench(wl, world, rank)
+    # the product path first (kernels and gathers pipelined over the block rows)
+    elapsed, _ = time_steps(b.step_pipelined, steps, warmup, barrier, use_dist, False)
+    el_seq, _ = time_steps(b.step_gather, steps, 2, barrier, use_dist, False)
+    el_loc, kernel_ms = time_steps(b.step_local, steps, 2, barrier, use_dist)
+    total_client = torch.tensor([b.client_bytes], dtype=torch.float64, device="cuda")
+    if use_dist:
+        dist.all_reduce(total_client)
+    total_client = float(total_client.item())
+
+    def form(el):
+        return {"value": round(total_client * steps / el / 1e9, 2), "unit": "GB/s",
+                "ms_per_step": round(el / steps * 1e3, 4)}
+    out = {"forms": {"no_collective": form(el_loc), "allgather": form(el_seq),
+                     "allgather_pipelined": form(elapsed)},
+           "roofline": roofline_of(b, kernel_ms, name),
+           "config": {"params_total": b.n_total, "params_per_gpu": b.map.n_local,
+                      "client_bytes_per_step_total": int(total_client),
+                      "block_rows": b.map.pieces, "block_elements": b.map.per,
+                      "gathered_bytes_per_gpu": 4 * b.map.P}}
+    del b
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -448,38 +479,41 @@ def main():
         torch.cuda.synchronize()
 
     if sharded:
-        b = ShardedBench(wl, world, rank)
-        # value: the product path (kernels and gathers pipelined over the block rows)
-        elapsed, _ = time_steps(b.step_pipelined, a.steps, a.warmup, barrier, use_dist, False)
-        el_seq, _ = time_steps(b.step_gather, a.steps, 2, barrier, use_dist, False)
-        el_loc, kernel_ms = time_steps(b.step_local, a.steps, 2, barrier, use_dist)
-        total_client = torch.tensor([b.client_bytes], dtype=torch.float64, device="cuda")
-        if use_dist:
-            dist.all_reduce(total_client)
-        total_client = float(total_client.item())
-
-        def form(el):
-            return {"value": round(total_client * a.steps / el / 1e9, 2), "unit": "GB/s",
-                    "ms_per_step": round(el / a.steps * 1e3, 4)}
+        m = measure_sharded(name, wl, world, rank, a.steps, a.warmup, barrier, use_dist)
+        extra = []
+        if not a.only:
+            # BASELINE configuration 3 (ResNet-50, K = 64, FedAdam / FedYogi on 1/2/4/8 GPUs), sharded
+            # the same way; every rank takes part (the gathers are collectives)
+            for other in SHARDED_EXTRA_WORKLOADS:
+                if other != name:
+                    e = measure_sharded(other, W.WORKLOADS[other], world, rank, a.steps, 2, barrier, use_dist)
+                    extra.append({"workload": other, "aggregator": W.WORKLOADS[other]["cls"],
+                                  "clients": W.WORKLOADS[other]["K"], **e["forms"]["allgather_pipelined"],
+                                  "params_total": e["config"]["params_total"],
+                                  "params_per_gpu": e["config"]["params_per_gpu"],
+                                  "block_rows": e["config"]["block_rows"],
+                                  "no_collective": e["forms"]["no_collective"],
+                                  "allgather": e["forms"]["allgather"],
+                                  "allgather_pipelined": e["forms"]["allgather_pipelined"],
+                                  "kernel": e["roofline"]["kernel"],
+                                  "kernel_avg_ms": e["roofline"]["kernel_avg_ms"],
+                                  "algorithmic_bytes_per_launch": e["roofline"]["algorithmic_bytes_per_launch"],
+                                  "frac": e["roofline"]["frac"]})
         if rank == 0:
             out = {
-                "metric": METRIC, **form(elapsed), "n_gpus": world, "steps": a.steps,
+                "metric": METRIC, **m["forms"]["allgather_pipelined"], "n_gpus": world, "steps": a.steps,
                 "warmup": a.warmup, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": name, "aggregator": wl["cls"], "clients": wl["K"],
-                           "params_total": b.n_total, "params_per_gpu": b.map.n_local,
-                           "client_bytes_per_step_total": int(total_client),
-                           "block_rows": b.map.pieces, "block_elements": b.map.per,
-                           "gathered_bytes_per_gpu": 4 * b.map.P,
+                "config": {"workload": name, "aggregator": wl["cls"], "clients": wl["K"], **m["config"],
                            "parallelism": f"parameter axis dealt in blocks to {world} GPUs; fused "
                                           "kernel per block row, RCCL all_gather_into_tensor per row, "
                                           "pipelined (value); N=1 counterpart of this workload: "
                                           "strong_scaling_reference of the one-GPU line"},
-                "no_collective": form(el_loc),
-                "allgather": form(el_seq),
-                "allgather_pipelined": form(elapsed),
-                "roofline": roofline_of(b, kernel_ms, name),
+                **m["forms"],
+                "roofline": m["roofline"],
             }
+            if extra:
+                out["workloads"] = extra
             print(json.dumps(out), flush=True)
         if use_dist:
             dist.destroy_process_group()

@@ -41,6 +41,12 @@ def test_one_rank_nccl_run_reports_the_three_sharded_forms():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1
     assert rf["algorithmic_bytes_per_launch"] == 4 * (64 + 6) * out["config"]["params_per_gpu"]
+    # the other ResNet-50 K = 64 optimizer rides along, dealt to the ranks the same way
+    (yogi,) = out["workloads"]
+    assert yogi["workload"] == "resnet50_fedyogi_k64" and yogi["params_total"] == 25557032
+    for form in ("no_collective", "allgather", "allgather_pipelined"):
+        assert yogi[form]["value"] > 0
+    assert yogi["value"] == yogi["allgather_pipelined"]["value"] and 0 < yogi["frac"] < 1
 
 
 def test_one_gpu_line_lists_every_benchmark_configuration():
