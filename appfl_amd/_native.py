@@ -26,6 +26,8 @@ _f = C.c_float
 _u64 = C.c_uint64
 
 FA_DT_F32, FA_DT_I64, FA_DT_I32 = range(3)
+FA_ADMM_KCHUNK, FA_ADMM_BLOCKS = 64, 2048
+FA_ADMM_RES_WS = 2 + 2 * FA_ADMM_BLOCKS
 
 
 class MeanSegment(C.Structure):
@@ -49,6 +51,8 @@ SIGNATURES = {
     "fa_server_opt_step": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _p]),
     "fa_apply_step": (_i, [_p, _p, _sz, _p]),
     "fa_weighted_mix": (_i, [_p, _p, _i, _p, _d, _i, _p, _sz, _p]),
+    "fa_admm_ii": (_i, [_p, _p, _p, _p, _i, _i, _p, _sz, _p, _p, _p, _p]),
+    "fa_admm_ice": (_i, [_p, _p, _p, _p, _i, _p, _sz, _p, _p, _p, _p]),
     "fa_mean_f32": (_i, [_p, _i, _p, _sz, _p]),
     "fa_mean_i64": (_i, [_p, _i, _p, _sz, _p]),
     "fa_mean_i32": (_i, [_p, _i, _p, _sz, _p]),

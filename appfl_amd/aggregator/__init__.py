@@ -1,5 +1,6 @@
 """Device aggregators under the names `appfl.algorithm.aggregator` uses for the CPU ones."""
 
+from .admm_aggregator import ICEADMMAggregator, IIADMMAggregator
 from .base_aggregator import BaseAggregator
 from .fedavg_aggregator import (FedAdagradAggregator, FedAdamAggregator, FedAvgAggregator,
                                 FedAvgMAggregator, FedYogiAggregator)
@@ -17,4 +18,6 @@ __all__ = [
     "FedBuffAggregator",
     "FedCompassAggregator",
     "FedQueueAggregator",
+    "IIADMMAggregator",
+    "ICEADMMAggregator",
 ]

@@ -191,6 +191,40 @@ def weighted_mix(x: Sequence, w: Sequence[float], g: torch.Tensor, mode: str, co
     N.check(rc, "fa_weighted_mix")
 
 
+def admm_carry_floats(n: int) -> int:
+    """Floats of the carry workspace an ADMM round of more than FA_ADMM_KCHUNK clients needs."""
+    return 2 * ((n + 3) // 4 * 4)
+
+
+def admm_round(alg: str, primal: Sequence, dual: Sequence, prev: Optional[Sequence],
+               penalty: Sequence[float], g: torch.Tensor, norms: torch.Tensor, res_ws: torch.Tensor,
+               num_clients: int = 1, carry_ws: Optional[torch.Tensor] = None,
+               n: Optional[int] = None) -> None:
+    """IIADMM ("ii": fa_admm_ii, the `dual` rows are updated in place) or ICEADMM ("ice":
+    fa_admm_ice) server update over ``g[:n]``; `norms` (2 float64) receives the primal and dual
+    residual norms, `res_ws` is the FA_ADMM_RES_WS-double workspace of the norm sums."""
+    n = g.numel() if n is None else n
+    K = len(primal)
+    if len(dual) != K or len(penalty) != K or (prev is not None and len(prev) != K):
+        raise ValueError("one dual row, one penalty (and one previous primal row) per client")
+    if norms.numel() < 2 or res_ws.numel() < N.FA_ADMM_RES_WS:
+        raise ValueError("norms needs 2 doubles, res_ws FA_ADMM_RES_WS doubles")
+    if carry_ws is not None and carry_ws.numel() < admm_carry_floats(n):
+        raise ValueError("carry workspace shorter than 2 * round_up(n, 4) floats")
+    f32, f64 = torch.float32, torch.float64
+    common = (_check_rows(primal, n, f32), _check_rows(dual, n, f32),
+              _check_rows(prev, n, f32) if prev is not None else None,
+              N.double_array([float(t) for t in penalty]), K)
+    tail = (_dev(g, f32), n, _dev(carry_ws, f32), _dev(res_ws, f64), _dev(norms, f64), _stream(g))
+    if alg == "ii":
+        rc = N.load().fa_admm_ii(*common, int(num_clients), *tail)
+    elif alg == "ice":
+        rc = N.load().fa_admm_ice(*common, *tail)
+    else:
+        raise ValueError(f"unknown ADMM flavour {alg!r}")
+    N.check(rc, "fa_admm_" + alg)
+
+
 _MEAN = {torch.float32: "fa_mean_f32", torch.float64: "fa_mean_f64", torch.int64: "fa_mean_i64",
          torch.int32: "fa_mean_i32"}
 _RAW = {torch.float32: "fa_buff_accum_raw_f32", torch.float64: "fa_buff_accum_raw_f64",

@@ -23,7 +23,7 @@ from . import aggregator as _dev
 
 NAMES = ("FedAvgAggregator", "FedAvgMAggregator", "FedAdamAggregator", "FedYogiAggregator",
          "FedAdagradAggregator", "FedAsyncAggregator", "FedBuffAggregator",
-         "FedCompassAggregator", "FedQueueAggregator")
+         "FedCompassAggregator", "FedQueueAggregator", "IIADMMAggregator", "ICEADMMAggregator")
 
 
 def register(prefix: str = "MI355X", replace: bool = False, module=None) -> Dict[str, type]:

@@ -222,6 +222,40 @@ int fa_weighted_mix(const float* const* x, const double* w, int K, float* g, dou
                     int mode, float* acc_ws, size_t n, fa_stream_t stream);
 
 /*
+ * ADMM server updates on flat fp32 vectors: K clients in call order, rows of K primal vectors,
+ * K dual vectors and (from the second round on) K previous primal vectors.
+ *
+ * fa_admm_ii -- IIADMM (algorithm/aggregator/iiadmm_aggregator.py:151-162; the server keeps the
+ * duals): per element, for k in 0..K-1
+ *     d = g - primal[k];  dual[k] = dual[k] + (float)penalty[k] * d        (written back)
+ *     acc = acc + (primal[k] - (float)(1.0 / penalty[k]) * dual[k])
+ * then g = acc / (float)num_clients   (num_clients: the client count of the first round, :54,162).
+ * fa_admm_ice -- ICEADMM (algorithm/aggregator/iceadmm_aggregator.py:147-166; clients send their
+ * duals): total = sum of penalty[] in client order (a double), per element
+ *     acc = acc + ((float)(penalty[k] / total) * primal[k] + (float)(1.0 / total) * dual[k]);  g = acc
+ * Both also produce the two residual norms of the round (iiadmm_aggregator.py:76-86,141-149;
+ * iceadmm_aggregator.py:72-82,137-145), with the g of BEFORE the update:
+ *     norms[0] = sqrt(sum_k sum_i (g - primal[k])^2)
+ *     norms[1] = sqrt(sum_i (sum_k (float)penalty[k] * (prev[k] - primal[k]))^2)    (0 when prev == NULL)
+ * The inner sums are fp32 in client order and the squares fp32, as the reference's tensor
+ * operations are; the sums over i are float64 in a fixed order (the reference adds fp32 tensors
+ * with torch.sum, whose order is its own: the norms agree to ~1e-6 relative, not bit for bit).
+ *
+ * primal, dual, prev, penalty: HOST arrays of K device pointers / K doubles.  g, norms (2
+ * doubles), res_ws (FA_ADMM_RES_WS doubles) and carry_ws: device memory.  carry_ws: 2 * ((n + 3)
+ * / 4 * 4) floats, only touched when K > FA_ADMM_KCHUNK (may be NULL otherwise).
+ */
+#define FA_ADMM_KCHUNK 64
+#define FA_ADMM_BLOCKS 2048
+#define FA_ADMM_RES_WS (2 + 2 * FA_ADMM_BLOCKS)
+int fa_admm_ii(const float* const* primal, float* const* dual, const float* const* prev,
+               const double* penalty, int K, int num_clients, float* g, size_t n, float* carry_ws,
+               double* res_ws, double* norms, fa_stream_t stream);
+int fa_admm_ice(const float* const* primal, const float* const* dual, const float* const* prev,
+                const double* penalty, int K, float* g, size_t n, float* carry_ws, double* res_ws,
+                double* norms, fa_stream_t stream);
+
+/*
  * FedAsync arrival (algorithm/aggregator/fedasync_aggregator.py:243-264 and :156-160).
  *   gradient_based == 0:  step = (float)alpha_t * (x - g)
  *   gradient_based == 1:  step = 0 - (float)alpha_t * x      (sub_form == 1, optimize_memory)

@@ -17,6 +17,8 @@ Reference files followed (relative to src/appfl/):
   algorithm/aggregator/fedadagrad_aggregator.py:21-118
   algorithm/aggregator/fedasync_aggregator.py:20-277
   algorithm/aggregator/fedbuff_aggregator.py:15-158
+  algorithm/aggregator/iiadmm_aggregator.py:19-171
+  algorithm/aggregator/iceadmm_aggregator.py:19-175
   misc/memory_utils.py:15-36, 75-131
 
 State dicts come in as ``{name: torch.Tensor | np.ndarray}`` and go out as
@@ -616,6 +618,131 @@ class OracleFedQueue(_OracleMixBase):
         return self._finish()
 
 
+class _OracleADMMBase(OracleBase):
+    """What iiadmm_aggregator.py and iceadmm_aggregator.py share: the model IS the global state
+    (re-read every round, :66-69 / :61-64), clients send {"primal", "penalty"[, "dual"]} or None
+    (:71-74 / :66-70), the primal residual (:76-86 / :72-82) and the dual residual
+    (:88-149 / :84-145).  The two residual norms are float64 sums here (the reference sums fp32
+    tensors in torch's own order, so they are compared under a tolerance)."""
+
+    def __init__(self, model, aggregator_configs=None, logger=None):
+        self.model = model
+        self.logger = logger
+        self.aggregator_configs = aggregator_configs
+        self.named_parameters = [n for n, _ in model.named_parameters()]
+        self.is_first_iter = True
+        self.penalty: Dict[Any, float] = {}
+        self.prim_res = 0
+        self.dual_res = 0
+        self.primal_states: Dict[Any, Dict[str, np.ndarray]] = {}
+        self.dual_states: Dict[Any, Dict[str, np.ndarray]] = {}
+        self.primal_states_curr: Dict[Any, Dict[str, np.ndarray]] = {}
+        self.primal_states_prev: Dict[Any, Dict[str, np.ndarray]] = {}
+
+    def _model_state(self) -> Dict[str, np.ndarray]:
+        return {k: to_np(v).copy() for k, v in self.model.state_dict().items()}
+
+    def get_parameters(self, **kwargs):
+        return self._model_state()
+
+    def _take(self, local_models, with_dual: bool) -> None:
+        for cid, m in local_models.items():
+            if m is not None:
+                self.primal_states[cid] = {n: to_np(m["primal"][n]).copy() for n in self.named_parameters}
+                if with_dual:
+                    self.dual_states[cid] = {n: to_np(m["dual"][n]).copy() for n in self.named_parameters}
+                self.penalty[cid] = m["penalty"]
+
+    def _residuals(self, local_models, g) -> None:
+        with np.errstate(over="ignore"):        # a square beyond fp32 is inf, as in torch
+            self._residuals_unchecked(local_models, g)
+
+    def _residuals_unchecked(self, local_models, g) -> None:
+        prim = 0.0
+        for cid in local_models:
+            for n in self.named_parameters:
+                d = g[n] - self.primal_states[cid][n]
+                prim += float(np.sum((d * d).astype(np.float64)))
+        self.prim_res = float(np.sqrt(prim))
+        if self.is_first_iter:
+            for cid in local_models:
+                self.primal_states_curr[cid] = {n: self.primal_states[cid][n].copy()
+                                                for n in self.named_parameters}
+            self.is_first_iter = False
+            return
+        self.primal_states_prev = {cid: {n: a.copy() for n, a in d.items()}
+                                   for cid, d in self.primal_states_curr.items()}
+        for cid in local_models:
+            self.primal_states_curr[cid] = {n: self.primal_states[cid][n].copy()
+                                            for n in self.named_parameters}
+        dual = 0.0
+        for n in self.named_parameters:
+            res = None
+            for cid in local_models:
+                t = (self.primal_states_prev[cid][n] - self.primal_states_curr[cid][n]) * _f32(self.penalty[cid])
+                res = t if res is None else res + t
+            dual += float(np.sum((res * res).astype(np.float64)))
+        self.dual_res = float(np.sqrt(dual))
+
+    def _finish(self, g):
+        import torch
+        self.model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in g.items()})
+        return g
+
+
+class OracleIIADMM(_OracleADMMBase):
+    """iiadmm_aggregator.py:50-165: the server keeps every client's dual; per parameter and
+    client, in client order: dual += penalty*(g - primal); acc += primal - (1/penalty)*dual;
+    then g = acc / num_clients (the client count of the FIRST round)."""
+
+    def aggregate(self, local_models, **kwargs):
+        g = self._model_state()
+        if not self.primal_states:
+            self.num_clients = len(local_models)
+            for cid in local_models:
+                self.primal_states[cid] = {}
+                self.primal_states_curr[cid] = {}
+                self.dual_states[cid] = {n: np.zeros_like(g[n]) for n in self.named_parameters}   # :60-64
+        self._take(local_models, with_dual=False)
+        self._residuals(local_models, g)
+        for n in self.named_parameters:                                                             # :151-162
+            acc = np.zeros_like(g[n])
+            for cid in local_models:
+                rho = self.penalty[cid]
+                x = self.primal_states[cid][n]
+                self.dual_states[cid][n] = self.dual_states[cid][n] + (g[n] - x) * _f32(rho)
+                acc = acc + (x - self.dual_states[cid][n] * _f32(1.0 / rho))
+            g[n] = acc / F32(self.num_clients)
+        return self._finish(g)
+
+
+class OracleICEADMM(_OracleADMMBase):
+    """iceadmm_aggregator.py:50-169: clients send their duals; per parameter, in client order:
+    g = sum_k ((penalty_k / total_penalty)*primal_k + (1/total_penalty)*dual_k)."""
+
+    def aggregate(self, local_models, **kwargs):
+        g = self._model_state()
+        if not self.primal_states:
+            self.num_clients = len(local_models)
+            for cid in local_models:
+                self.primal_states[cid] = {}
+                self.dual_states[cid] = {}
+                self.primal_states_curr[cid] = {}
+        self._take(local_models, with_dual=True)
+        self._residuals(local_models, g)
+        total = 0
+        for cid in local_models:                                                                    # :147-149
+            total += self.penalty[cid]
+        for n in self.named_parameters:                                                             # :151-166
+            acc = np.zeros_like(g[n])
+            for cid in local_models:
+                a = self.primal_states[cid][n] * _f32(self.penalty[cid] / total)
+                b = self.dual_states[cid][n] * _f32(1.0 / total)
+                acc = acc + (a + b)
+            g[n] = acc
+        return self._finish(g)
+
+
 ORACLES = {
     "FedAvgAggregator": OracleFedAvg,
     "FedAvgMAggregator": OracleFedAvgM,
@@ -626,4 +753,6 @@ ORACLES = {
     "FedBuffAggregator": OracleFedBuff,
     "FedCompassAggregator": OracleFedCompass,
     "FedQueueAggregator": OracleFedQueue,
+    "IIADMMAggregator": OracleIIADMM,
+    "ICEADMMAggregator": OracleICEADMM,
 }

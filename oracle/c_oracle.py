@@ -126,6 +126,22 @@ def buff_flush_mean(g, step, K) -> None:
     getattr(load(), fn)(_ptr(g), _ptr(_chk(step, g.dtype)), C.c_int(K), C.c_size_t(g.size))
 
 
+def admm(alg: str, primal, dual, prev, penalty, num_clients: int, g):
+    """IIADMM ("ii": `dual` rows are updated in place) / ICEADMM ("ice") server update on flat
+    vectors; returns (primal residual, dual residual)."""
+    n = g.size
+    for a in list(primal) + list(dual) + list(prev or []):
+        _chk(a, np.float32)
+        assert a.size == n
+    res = (C.c_double * 2)()
+    pa = (C.c_double * len(penalty))(*[float(t) for t in penalty])
+    rc = load().or_admm(C.c_int({"ii": 0, "ice": 1}[alg]), _ptrs(primal), _ptrs(dual),
+                        _ptrs(prev) if prev else None, pa, C.c_int(len(primal)), C.c_int(num_clients),
+                        _ptr(_chk(g, np.float32)), C.c_size_t(n), res)
+    assert rc == 0, rc
+    return float(res[0]), float(res[1])
+
+
 def synth_fill(n: int, seed: int, first: int = 0, scale: float = 1.0,
                base: Optional[np.ndarray] = None) -> np.ndarray:
     out = np.empty(n, dtype=np.float32)

@@ -18,6 +18,8 @@
  *   algorithm/aggregator/fedadagrad_aggregator.py :59-91
  *   algorithm/aggregator/fedasync_aggregator.py   :243-264, :156-160
  *   algorithm/aggregator/fedbuff_aggregator.py    :75-88, :145-158
+ *   algorithm/aggregator/iiadmm_aggregator.py     :76-86, :137-162
+ *   algorithm/aggregator/iceadmm_aggregator.py    :72-82, :133-166
  *   misc/memory_utils.py                          :95-131
  */
 #include <math.h>
@@ -281,6 +283,65 @@ void or_buff_flush_mean_i64(int64_t* g, const int64_t* step, int K, size_t n) {
 void or_buff_flush_mean_i32(int32_t* g, const int32_t* step, int K, size_t n) {
     const float kf = (float)K;
     for (size_t i = 0; i < n; ++i) g[i] = (int32_t)((float)step[i] / kf);
+}
+
+/*
+ * ADMM server updates on flat vectors (iiadmm_aggregator.py:76-86,137-162;
+ * iceadmm_aggregator.py:72-82,133-166).  K clients in call order; penalty holds the Python
+ * doubles, each rounded to fp32 where it multiplies a tensor.  prev may be NULL (first round:
+ * no dual residual).  res[0] / res[1] receive the primal / dual residual norms; the squares are
+ * fp32 like torch.square's, their sums float64 (the reference sums in torch's own order, so the
+ * norms are compared under a tolerance).  alg 0: IIADMM (dual rows updated in place, g =
+ * sum(primal - (1/penalty)*dual) / num_clients), alg 1: ICEADMM (g = sum((penalty/total)*primal +
+ * (1/total)*dual)).
+ */
+int or_admm(int alg, const float* const* primal, float* const* dual, const float* const* prev,
+            const double* penalty, int K, int num_clients, float* g, size_t n, double* res) {
+    if (K <= 0 || K > 65536 || alg < 0 || alg > 1) return -1;
+    float rho[K], c1[K];
+    double total = 0.0;
+    for (int k = 0; k < K; ++k) total += penalty[k];
+    for (int k = 0; k < K; ++k) {
+        rho[k] = (float)penalty[k];
+        c1[k] = alg == 0 ? (float)(1.0 / penalty[k]) : (float)(penalty[k] / total);
+    }
+    const float c2 = (float)(1.0 / total), nc = (float)num_clients;
+    double prim = 0.0, du2 = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : prim, du2)
+    for (size_t i = 0; i < n; ++i) {
+        const float gi = g[i];
+        float acc = 0.0f, r = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float x = primal[k][i];
+            const float d = gi - x;
+            const float d2 = d * d;
+            prim += (double)d2;
+            if (alg == 0) {
+                const float pd = rho[k] * d;
+                const float du = dual[k][i] + pd;
+                dual[k][i] = du;
+                const float t = c1[k] * du;
+                const float u = x - t;
+                acc = acc + u;
+            } else {
+                const float a = c1[k] * x;
+                const float b = c2 * dual[k][i];
+                const float s = a + b;
+                acc = acc + s;
+            }
+            if (prev) {
+                const float dp = prev[k][i] - x;
+                const float t = rho[k] * dp;
+                r = r + t;
+            }
+        }
+        g[i] = alg == 0 ? acc / nc : acc;
+        const float r2 = r * r;
+        du2 += (double)r2;
+    }
+    res[0] = sqrt(prim);
+    res[1] = prev ? sqrt(du2) : 0.0;
+    return 0;
 }
 
 /* Counter-based synthetic inputs shared with the device generator. */

@@ -50,7 +50,9 @@ MIXED64 = {
     "b.weight": ((37, 5), "f64"),
     "b.bias": ((37,), "f64"),
 }
-SPECS = {"toy": TOY, "ragged": RAGGED, "big": BIG, "mixed64": MIXED64}
+# one large parameter with an odd element count and its bias (ADMM scenarios: 128-bit body + tail)
+LINEAR = {"l.weight": ((257, 1001), "f32"), "l.bias": ((257,), "f32")}
+SPECS = {"toy": TOY, "ragged": RAGGED, "big": BIG, "mixed64": MIXED64, "linear": LINEAR}
 
 _NP = {"f32": np.float32, "f64": np.float64, "i64": np.int64, "i32": np.int32}
 
@@ -101,13 +103,28 @@ class Mixed64Model(torch.nn.Module):
             self.bn.running_var.abs_().add_(1.0)
 
 
+class LinearModel(torch.nn.Module):
+    """One linear layer with the LINEAR entry names."""
+
+    def __init__(self):
+        super().__init__()
+        self.l = torch.nn.Linear(1001, 257)
+        with torch.no_grad():
+            for i, (name, t) in enumerate(self.state_dict().items()):
+                t.copy_(torch.from_numpy(synth.fill(t.numel(), 700 + i, scale=0.05).reshape(tuple(t.shape))))
+
+
+MODELS = {"toy": ToyModel, "mixed64": Mixed64Model, "linear": LinearModel}
+
+
 def _name_seed(name: str) -> int:
     return sum((i + 1) * ord(c) for i, c in enumerate(name)) % 100000
 
 
 def make_state(spec: Dict, seed: int, base_seed: int = 7, scale: float = 0.02,
-               gradient: bool = False) -> Dict[str, torch.Tensor]:
-    """One client's state dict: common base (seed 7) + small client-specific noise."""
+               gradient: bool = False, huge: bool = True) -> Dict[str, torch.Tensor]:
+    """One client's state dict: common base (seed 7) + small client-specific noise (`huge`: some
+    clients also carry one value of 3e30)."""
     out = {}
     for name, (shape, kind) in spec.items():
         n = int(np.prod(shape)) if shape else 1
@@ -131,7 +148,7 @@ def make_state(spec: Dict, seed: int, base_seed: int = 7, scale: float = 0.02,
                 # edge values: exact base (zero difference), a signed zero, a huge value, a denormal
                 a[1] = 0.0 if gradient else synth.fill(n, base_seed * 131 + ns, scale=0.05)[1]
                 a[2] = -0.0
-                if seed % 3 == 0:
+                if huge and seed % 3 == 0:
                     a[3] = 3.0e30
                 a[4] = 1e-41
         else:
@@ -402,9 +419,39 @@ def float64_scenarios() -> List[Dict]:
     return out
 
 
+# ADMM rounds: (client, penalty) in arrival order; penalty None = the client sent no model this
+# round (the aggregators then keep its previous primal / dual / penalty).  Round 2 is a subset in
+# another order, round 4 changes every penalty.
+ADMM_SCRIPT = [
+    [(0, 500.0), (1, 250.0), (2, 1000.0)],
+    [(0, 500.0), (1, 125.0), (2, 1000.0)],
+    [(2, 2000.0), (0, 500.0)],
+    [(0, 500.0), (1, None), (2, 1000.0)],
+    [(1, 62.5), (2, 1.0 / 3.0), (0, 7.7)],
+]
+# records of the two residual norms (Python floats from torch.sum over fp32 tensors, whose
+# summation order is torch's own): compared under this relative tolerance, everything else in an
+# ADMM scenario bit for bit
+RESIDUAL_LABEL = ".residuals"
+RESIDUAL_RTOL = 1e-5
+
+
+def admm_scenarios() -> List[Dict]:
+    """IIADMM / ICEADMM server updates (iiadmm_aggregator.py:50-165, iceadmm_aggregator.py:50-169):
+    clients send {"primal": state dict, "penalty": float} (ICEADMM also "dual")."""
+    out = []
+    for cls in ("IIADMMAggregator", "ICEADMMAggregator"):
+        for spec, optmem in (("toy", True), ("toy", False), ("linear", True)):
+            out.append({"id": f"{cls[:-10]}-{spec}-{'opt' if optmem else 'orig'}", "kind": "admm",
+                        "cls": cls, "spec": spec, "model": True, "cfg": {"optimize_memory": optmem},
+                        "script": ADMM_SCRIPT, "sample_sizes": {}, "huge": not optmem})
+    return out
+
+
 def all_scenarios() -> List[Dict]:
     return (sync_scenarios() + async_scenarios() + chunked_scenarios() + mix_scenarios()
-            + secure_scenarios() + getparams_scenarios() + sched_scenarios() + float64_scenarios())
+            + secure_scenarios() + getparams_scenarios() + sched_scenarios() + float64_scenarios()
+            + admm_scenarios())
 
 
 def _meta_record(meta: Dict) -> Dict[str, np.ndarray]:
@@ -546,7 +593,7 @@ def run_scenario(factory: Callable, sc: Dict, schedulers: Callable = default_sch
     aggregator in the scheduler-driven scenarios (default: the package's stand-ins; the golden
     generator passes the reference's own)."""
     spec = SPECS[sc["spec"]]
-    model = (Mixed64Model() if sc["spec"] == "mixed64" else ToyModel()) if sc["model"] else None
+    model = MODELS.get(sc["spec"], ToyModel)() if sc["model"] else None
     agg = factory(sc["cls"], model, dict(sc["cfg"]))
     for cid, n in sc["sample_sizes"].items():
         agg.set_client_sample_size(cid, n)
@@ -559,7 +606,30 @@ def run_scenario(factory: Callable, sc: Dict, schedulers: Callable = default_sch
     rec: List[Tuple[str, Dict]] = []
     if model is not None:
         rec.append(("initial", _snap(agg.get_parameters())))
-    if sc["kind"] == "sync":
+    if sc["kind"] == "admm":
+        named = [n for n, _ in model.named_parameters()]
+        for r, clients in enumerate(sc["script"]):
+            local = {}
+            for cid, penalty in clients:
+                if penalty is None:
+                    local[cid] = None
+                    continue
+                huge = sc.get("huge", False)     # its square overflows fp32: both norms become inf
+                payload = {"primal": make_state(spec, seed=7000 + 61 * r + cid, huge=huge),
+                           "penalty": penalty}
+                if sc["cls"] == "ICEADMMAggregator":
+                    dual = make_state(spec, seed=7500 + 61 * r + cid, gradient=True, scale=0.5, huge=huge)
+                    payload["dual"] = {n: dual[n] for n in named}
+                local[cid] = payload
+            rec.append((f"round{r}", _snap(agg.aggregate(local))))
+            rec.append((f"round{r}{RESIDUAL_LABEL}", {"prim_res": np.array(agg.prim_res, np.float64),
+                                                     "dual_res": np.array(agg.dual_res, np.float64)}))
+            if sc["cls"] == "IIADMMAggregator":
+                rec.append((f"round{r}.dual_states",
+                            _snap({f"{cid}/{n}": agg.dual_states[cid][n] for cid in sorted(agg.dual_states)
+                                   for n in named})))
+        rec.append(("final_get_parameters", _snap(agg.get_parameters())))
+    elif sc["kind"] == "sync":
         for r, K in enumerate(sc["rounds"]):
             cids = [(r + j) % max(6, K) for j in range(K)]
             local = {}
