@@ -26,8 +26,26 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
+#ifndef FA_ADMM_AHEAD
+#define FA_ADMM_AHEAD 4
+#endif
+#ifndef FA_ADMM_VPT
+#define FA_ADMM_VPT 2
+#endif
+#ifndef FA_ADMM_DUAL_NT
+#define FA_ADMM_DUAL_NT 1
+#endif
+#ifndef FA_ADMM_WT
+#define FA_ADMM_WT 1
+#endif
+#ifndef FA_ADMM_XCD
+#define FA_ADMM_XCD 32
+#endif
+#ifndef FA_ADMM_GRID
+#define FA_ADMM_GRID FA_ADMM_BLOCKS
+#endif
 constexpr int kThreads = 256;
-constexpr int kAhead = 4;                       // clients whose loads are in flight together
+constexpr int kAhead = FA_ADMM_AHEAD;           // clients whose loads are in flight together
 constexpr unsigned kMaxBlocks = FA_ADMM_BLOCKS; // one pair of partial sums per block
 constexpr size_t kSegment = size_t(1) << 29;    // elements one launch indexes with 32-bit vector indices
 
@@ -105,13 +123,56 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
     return s;
 }
 
-template <int ALG, int VEC, int VPT>
+// One client's contribution to the vectors a thread owns; everything stays in registers.
+template <int ALG, int VEC, bool PREV>
+__device__ __forceinline__ void admm_fold(const AdmmArgs& a, int k, const Pk<VEC>& g, const Pk<VEC>& xv,
+                                          Pk<VEC>& du, const Pk<VEC>& pv, Pk<VEC>& acc, Pk<VEC>& r,
+                                          bool ok, double& prim) {
+    const float rho = a.rho[k], c1 = a.c1[k];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float x = xv.e[j];
+        const float d = g.e[j] - x;
+        const float d2 = d * d;
+        if (ok) prim += static_cast<double>(d2);
+        if (ALG == kII) {
+            const float pd = rho * d;
+            const float dn = du.e[j] + pd;
+            du.e[j] = dn;
+            const float tt = c1 * dn;
+            const float uu = x - tt;
+            acc.e[j] = acc.e[j] + uu;
+        } else {
+            const float aa = c1 * x;
+            const float bb = a.c2 * du.e[j];
+            const float ss = aa + bb;
+            acc.e[j] = acc.e[j] + ss;
+        }
+        if (PREV) {
+            const float dp = pv.e[j] - x;
+            const float tp = rho * dp;
+            r.e[j] = r.e[j] + tp;
+        }
+    }
+}
+
+// PREV: the previous-primal rows are read and the dual residual is formed.
+template <int ALG, int VEC, int VPT, bool PREV>
 __global__ __launch_bounds__(kThreads) void admm_kernel(const AdmmArgs a) {
     __shared__ double lds[kThreads / 64];
     constexpr unsigned kTile = kThreads * VPT;
     const unsigned tiles = (a.n + kTile - 1) / kTile;
     double prim = 0.0, dual2 = 0.0;
-    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+    for (unsigned t0 = blockIdx.x; t0 < tiles; t0 += gridDim.x) {
+        unsigned t = t0;
+        // Blocks go round-robin to the 8 XCDs: inside windows of 8*R tiles every XCD takes R
+        // consecutive tiles instead of every eighth one (measured +2-3 %); a ragged last window
+        // keeps the plain order.
+        if (VEC == 4) {
+            constexpr unsigned R = FA_ADMM_XCD;
+            const unsigned win = t0 & ~(8u * R - 1u);
+            if (win + 8u * R <= tiles) t = win + (t0 & 7u) * R + ((t0 >> 3) & (R - 1u));
+        }
         unsigned idx[VPT];
         bool ok[VPT];
 #pragma unroll
@@ -130,60 +191,48 @@ __global__ __launch_bounds__(kThreads) void admm_kernel(const AdmmArgs a) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[q].e[j] = 0.0f;
             }
-            if (a.has_prev && a.res_in) {
+            if (PREV && a.res_in) {
                 r[q] = ld<VEC>(a.res_in, idx[q], false);
             } else {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) r[q].e[j] = 0.0f;
             }
         }
-        for (int k0 = 0; k0 < a.K; k0 += kAhead) {
+        int k = 0;
+        // whole batches: the client indices are k .. k + kAhead - 1 with no clamping, so the row
+        // pointers of a batch come in with a few wide scalar loads
+        for (; k + kAhead <= a.K; k += kAhead) {
             Pk<VEC> xv[kAhead][VPT], dv[kAhead][VPT], pv[kAhead][VPT];
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                const int k = (k0 + u < a.K) ? k0 + u : a.K - 1;
 #pragma unroll
                 for (int q = 0; q < VPT; ++q) {
-                    xv[u][q] = ld<VEC>(a.x[k], idx[q], true);
-                    dv[u][q] = ld<VEC>(a.d[k], idx[q], true);
-                    if (a.has_prev) pv[u][q] = ld<VEC>(a.p[k], idx[q], true);
+                    xv[u][q] = ld<VEC>(a.x[k + u], idx[q], true);
+                    dv[u][q] = ld<VEC>(a.d[k + u], idx[q], FA_ADMM_DUAL_NT != 0);
+                    if (PREV) pv[u][q] = ld<VEC>(a.p[k + u], idx[q], true);
                 }
             }
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
-                if (k0 + u >= a.K) break;
-                const int k = k0 + u;
-                const float rho = a.rho[k], c1 = a.c1[k];
 #pragma unroll
                 for (int q = 0; q < VPT; ++q) {
-                    Pk<VEC> du = dv[u][q];
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        const float x = xv[u][q].e[j];
-                        const float d = g[q].e[j] - x;
-                        const float d2 = d * d;
-                        if (ok[q]) prim += static_cast<double>(d2);
-                        if (ALG == kII) {
-                            const float pd = rho * d;
-                            const float dn = du.e[j] + pd;
-                            du.e[j] = dn;
-                            const float tt = c1 * dn;
-                            const float uu = x - tt;
-                            acc[q].e[j] = acc[q].e[j] + uu;
-                        } else {
-                            const float aa = c1 * x;
-                            const float bb = a.c2 * du.e[j];
-                            const float ss = aa + bb;
-                            acc[q].e[j] = acc[q].e[j] + ss;
-                        }
-                        if (a.has_prev) {
-                            const float dp = pv[u][q].e[j] - x;
-                            const float tp = rho * dp;
-                            r[q].e[j] = r[q].e[j] + tp;
-                        }
-                    }
-                    if (ALG == kII && ok[q]) st<VEC>(a.d[k], idx[q], du, a.wt);
+                    admm_fold<ALG, VEC, PREV>(a, k + u, g[q], xv[u][q], dv[u][q], pv[u][q], acc[q], r[q], ok[q], prim);
+                    if (ALG == kII && ok[q]) st<VEC>(a.d[k + u], idx[q], dv[u][q], a.wt);
                 }
+            }
+        }
+        for (; k < a.K; ++k) {
+            Pk<VEC> xv[VPT], dv[VPT], pv[VPT];
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+                xv[q] = ld<VEC>(a.x[k], idx[q], true);
+                dv[q] = ld<VEC>(a.d[k], idx[q], FA_ADMM_DUAL_NT != 0);
+                if (PREV) pv[q] = ld<VEC>(a.p[k], idx[q], true);
+            }
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+                admm_fold<ALG, VEC, PREV>(a, k, g[q], xv[q], dv[q], pv[q], acc[q], r[q], ok[q], prim);
+                if (ALG == kII && ok[q]) st<VEC>(a.d[k], idx[q], dv[q], a.wt);
             }
         }
 #pragma unroll
@@ -191,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void admm_kernel(const AdmmArgs a) {
             if (!ok[q]) continue;
             if (!a.last) {
                 st<VEC>(a.acc_out, idx[q], acc[q], a.wt);
-                if (a.has_prev) st<VEC>(a.res_out, idx[q], r[q], a.wt);
+                if (PREV) st<VEC>(a.res_out, idx[q], r[q], a.wt);
                 continue;
             }
             Pk<VEC> out;
@@ -199,7 +248,7 @@ __global__ __launch_bounds__(kThreads) void admm_kernel(const AdmmArgs a) {
             for (int j = 0; j < VEC; ++j) {
                 out.e[j] = (ALG == kII) ? acc[q].e[j] / a.nclients : acc[q].e[j];
                 const float r2 = r[q].e[j] * r[q].e[j];
-                if (a.has_prev) dual2 += static_cast<double>(r2);
+                if (PREV) dual2 += static_cast<double>(r2);
             }
             st<VEC>(a.g, idx[q], out, a.wt);
         }
@@ -212,10 +261,10 @@ __global__ __launch_bounds__(kThreads) void admm_kernel(const AdmmArgs a) {
     }
 }
 
-// Adds the `blocks` pairs a launch left in ws[2..] to the running totals ws[0..1], in a fixed
-// order; `finish`: also writes the two norms.
-__global__ __launch_bounds__(kThreads) void admm_totals_kernel(double* ws, unsigned blocks, int finish,
-                                                             double* norms) {
+// Adds the `blocks` pairs a launch left in ws[2..] to the running totals ws[0..1] (`first`: the
+// totals start from zero), in a fixed order; `finish`: also writes the two norms.
+__global__ __launch_bounds__(kThreads) void admm_totals_kernel(double* ws, unsigned blocks, int first,
+                                                             int finish, double* norms) {
     __shared__ double lds[kThreads / 64];
     double p = 0.0, d = 0.0;
     for (unsigned b = threadIdx.x; b < blocks; b += kThreads) {
@@ -225,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void admm_totals_kernel(double* ws, unsig
     const double ps = block_sum(p, lds);
     const double ds = block_sum(d, lds);
     if (threadIdx.x == 0) {
-        const double tp = ws[0] + ps, td = ws[1] + ds;
+        const double tp = (first ? 0.0 : ws[0]) + ps, td = (first ? 0.0 : ws[1]) + ds;
         ws[0] = tp;
         ws[1] = td;
         if (finish) {
@@ -238,19 +287,24 @@ __global__ __launch_bounds__(kThreads) void admm_totals_kernel(double* ws, unsig
 inline int hip_code(hipError_t e) { return e == hipSuccess ? FA_OK : FA_ERR_HIP - static_cast<int>(e); }
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-template <int ALG>
-int launch_admm(const AdmmArgs& a, bool vec, hipStream_t st) {
+template <int ALG, bool PREV>
+int launch_admm_p(const AdmmArgs& a, bool vec, hipStream_t st) {
     if (vec) {
-        constexpr int VPT = 2;
+        constexpr int VPT = FA_ADMM_VPT;
         const size_t tiles = (static_cast<size_t>(a.n) + kThreads * VPT - 1) / (kThreads * VPT);
-        const unsigned grid = static_cast<unsigned>(tiles > kMaxBlocks ? kMaxBlocks : tiles);
-        hipLaunchKernelGGL((admm_kernel<ALG, 4, VPT>), dim3(grid), dim3(kThreads), 0, st, a);
+        const unsigned grid = static_cast<unsigned>(tiles > FA_ADMM_GRID ? FA_ADMM_GRID : tiles);
+        hipLaunchKernelGGL((admm_kernel<ALG, 4, VPT, PREV>), dim3(grid), dim3(kThreads), 0, st, a);
         return static_cast<int>(grid);
     }
     const size_t tiles = (static_cast<size_t>(a.n) + kThreads - 1) / kThreads;
     const unsigned grid = static_cast<unsigned>(tiles > kMaxBlocks ? kMaxBlocks : tiles);
-    hipLaunchKernelGGL((admm_kernel<ALG, 1, 1>), dim3(grid), dim3(kThreads), 0, st, a);
+    hipLaunchKernelGGL((admm_kernel<ALG, 1, 1, PREV>), dim3(grid), dim3(kThreads), 0, st, a);
     return static_cast<int>(grid);
+}
+
+template <int ALG>
+int launch_admm(const AdmmArgs& a, bool vec, hipStream_t st) {
+    return a.has_prev ? launch_admm_p<ALG, true>(a, vec, st) : launch_admm_p<ALG, false>(a, vec, st);
 }
 
 int admm_dispatch(int alg, const float* const* primal, float* const* dual, const float* const* prev,
@@ -270,10 +324,9 @@ int admm_dispatch(int alg, const float* const* primal, float* const* dual, const
         total += penalty[k];   // iceadmm_aggregator.py:147-149: a Python sum in client order
     }
     if (!a4) return FA_ERR_ALIGN;
-    hipError_t e = hipMemsetAsync(res_ws, 0, 2 * sizeof(double), st);
-    if (e != hipSuccess) return hip_code(e);
+    hipError_t e = hipSuccess;
     if (n == 0) {
-        hipLaunchKernelGGL(admm_totals_kernel, dim3(1), dim3(kThreads), 0, st, res_ws, 0u, 1, norms);
+        hipLaunchKernelGGL(admm_totals_kernel, dim3(1), dim3(kThreads), 0, st, res_ws, 0u, 1, 1, norms);
         return hip_code(hipGetLastError());
     }
     // ranges of the flat axis: <= kSegment pieces, each a 128-bit body and a scalar tail
@@ -289,6 +342,7 @@ int admm_dispatch(int alg, const float* const* primal, float* const* dual, const
     }
     float* acc_ws = carry_ws;
     float* rvec_ws = carry_ws ? carry_ws + (n + 3) / 4 * 4 : nullptr;   // 16-byte aligned like acc_ws
+    int first = 1;
     for (int ri = 0; ri < nr; ++ri) {
         const Range& rg = ranges[ri];
         for (int k0 = 0; k0 < K; k0 += FA_ADMM_KCHUNK) {
@@ -315,13 +369,14 @@ int admm_dispatch(int alg, const float* const* primal, float* const* dual, const
             a.n = static_cast<unsigned>(rg.cnt);
             a.K = kc;
             a.has_prev = prev ? 1 : 0;
-            a.wt = 1;
+            a.wt = FA_ADMM_WT;
             const int grid = alg == kII ? launch_admm<kII>(a, rg.vec, st) : launch_admm<kICE>(a, rg.vec, st);
             e = hipGetLastError();
             if (e != hipSuccess) return hip_code(e);
             const int finish = (ri == nr - 1 && a.last) ? 1 : 0;
             hipLaunchKernelGGL(admm_totals_kernel, dim3(1), dim3(kThreads), 0, st, res_ws,
-                               static_cast<unsigned>(grid), finish, norms);
+                               static_cast<unsigned>(grid), first, finish, norms);
+            first = 0;
             e = hipGetLastError();
             if (e != hipSuccess) return hip_code(e);
         }

@@ -122,6 +122,9 @@ WORKLOADS: Dict[str, Dict] = {
     "resnet50_fedavgm_k64": {"table": lambda: resnet(50), "cls": "FedAvgMAggregator", "K": 64},
     "vitb16_fedasync": {"table": vit_b_16, "cls": "FedAsyncAggregator", "K": 1},
     "vitb16_fedbuff_k16": {"table": vit_b_16, "cls": "FedBuffAggregator", "K": 16},
+    # ADMM server updates: K clients' primal, dual and previous-primal rows resident in HBM
+    "resnet50_iiadmm_k16": {"table": lambda: resnet(50), "cls": "IIADMMAggregator", "K": 16},
+    "resnet50_iceadmm_k16": {"table": lambda: resnet(50), "cls": "ICEADMMAggregator", "K": 16},
     "flat162m_fedavg_k32": {"table": lambda: flat(162_500_000), "cls": "FedAvgAggregator", "K": 32},
     # the whole 1.3 B-parameter vector on ONE GPU: 166 GB of client rows in HBM
     "flat1300m_fedavg_k32": {"table": lambda: flat(1_300_000_000), "cls": "FedAvgAggregator", "K": 32},

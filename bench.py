@@ -47,7 +47,7 @@ SHARDED_WORKLOAD = "flat1300m_fedavg_k32"
 NORTH_STAR_WORKLOAD = "resnet50_fedadam_k64"
 SHARDED_EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64"]
 EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "flat162m_fedavg_k32",
-                   "vitb16_fedasync", "vitb16_fedbuff_k16"]
+                   "vitb16_fedasync", "vitb16_fedbuff_k16", "resnet50_iiadmm_k16", "resnet50_iceadmm_k16"]
 _OPT_OF = {"FedAvgAggregator": "none", "FedAvgMAggregator": "avgm", "FedAdamAggregator": "adam",
            "FedYogiAggregator": "yogi", "FedAdagradAggregator": "adagrad"}
 STATE_VECTORS = {"none": 2, "avgm": 4, "adam": 6, "yogi": 6, "adagrad": 6}  # g/m/v reads + writes
@@ -161,6 +161,60 @@ class AsyncBench:
 
     def result(self):
         return self.agg._flats["f32"][:self.result_numel]
+
+
+class AdmmBench:
+    """IIADMM / ICEADMM workload: K clients' primal, dual and previous-primal rows of the model's
+    parameters in HBM, one server update (fa_admm_ii / fa_admm_ice) per step.  The timed call
+    includes the small launches that total the residual norms."""
+
+    def __init__(self, wl, rank):
+        from appfl_amd import _native as N, ops, workloads as W
+        self.ops = ops
+        rows = wl["table"]()
+        n = self.n_step = W.numel([r for r in rows if r[2] == torch.float32], params_only=True)
+        K = self.K = wl["K"]
+        self.alg = "ii" if wl["cls"] == "IIADMMAggregator" else "ice"
+        stride = (n + 63) // 64 * 64
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.g = torch.empty(n, dtype=torch.float32, device=dev)
+        ops.synth_fill(self.g, 7 + 1000003 * rank, scale=0.05)
+        self.slabs = torch.empty((3, K, stride), dtype=torch.float32, device=dev)
+        for k in range(K):
+            ops.synth_fill(self.slabs[0, k], 1000 + k, scale=0.01, base=self.g, n=n)     # primal
+            ops.synth_fill(self.slabs[1, k], 3000 + k, scale=0.5, n=n)                   # dual
+            ops.synth_fill(self.slabs[2, k], 2000 + k, scale=0.01, base=self.g, n=n)     # previous primal
+        self.rows = [[self.slabs[j, k] for k in range(K)] for j in range(3)]
+        self.penalty = [500.0 / (1 + k % 4) for k in range(K)]
+        self.norms = torch.zeros(2, dtype=torch.float64, device=dev)
+        self.res_ws = torch.empty(N.FA_ADMM_RES_WS, dtype=torch.float64, device=dev)
+        self.carry = (torch.empty(ops.admm_carry_floats(n), dtype=torch.float32, device=dev)
+                      if K > N.FA_ADMM_KCHUNK else None)
+        self.kernel = "admm_kernel<%s>" % self.alg
+        # per client and parameter: primal, dual, previous primal read (+ dual written back by
+        # IIADMM); g read and written once
+        self.alg_bytes = 4 * ((4 if self.alg == "ii" else 3) * K + 2) * n
+        self.client_bytes = 4 * (1 if self.alg == "ii" else 2) * K * n      # what the clients sent
+        self.result_numel = n
+
+    def step(self, events=None):
+        if events:
+            events[0].record()
+        self.ops.admm_round(self.alg, self.rows[0], self.rows[1], self.rows[2], self.penalty, self.g,
+                            self.norms, self.res_ws, num_clients=self.K, carry_ws=self.carry, n=self.n_step)
+        if events:
+            events[1].record()
+
+    def result(self):
+        return self.g
+
+
+def bench_class(wl):
+    if wl["cls"] in ("FedAsyncAggregator", "FedBuffAggregator"):
+        return AsyncBench
+    if wl["cls"] in ("IIADMMAggregator", "ICEADMMAggregator"):
+        return AdmmBench
+    return SyncBench
 
 
 def cpu_baseline(wl, budget_s):
@@ -406,8 +460,7 @@ def measure_workload(name, steps, warmup, barrier):
     """One extra workload on this GPU: same timing as the headline, its objects freed after."""
     from appfl_amd import workloads as W
     wl = W.WORKLOADS[name]
-    is_async = wl["cls"] in ("FedAsyncAggregator", "FedBuffAggregator")
-    b = (AsyncBench if is_async else SyncBench)(wl, 0)
+    b = bench_class(wl)(wl, 0)
     elapsed, kernel_ms = time_steps(b.step, steps, warmup, barrier, False)
     r = roofline_of(b, kernel_ms, name)
     out = {"workload": name, "aggregator": wl["cls"], "clients": wl["K"], "steps": steps,
@@ -468,7 +521,7 @@ def main():
     if name not in W.WORKLOADS:
         raise SystemExit(f"unknown workload {name}; choose from {sorted(W.WORKLOADS)}")
     wl = W.WORKLOADS[name]
-    is_async = wl["cls"] in ("FedAsyncAggregator", "FedBuffAggregator")
+    is_async = wl["cls"] in ("FedAsyncAggregator", "FedBuffAggregator", "IIADMMAggregator", "ICEADMMAggregator")
     if sharded and is_async:
         raise SystemExit("the sharded benchmark takes a FedAvg-family workload")
 
@@ -519,7 +572,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    b = (AsyncBench if is_async else SyncBench)(wl, rank)
+    b = bench_class(wl)(wl, rank)
     elapsed, kernel_ms = time_steps(b.step, a.steps, a.warmup, barrier, use_dist)
     if rank == 0:
         out = {
@@ -563,7 +616,7 @@ def main():
                     torch.cuda.empty_cache()
             if not a.no_end_to_end and not is_async:
                 out["end_to_end"] = end_to_end(wl)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and bench_class(wl) is not AdmmBench:
             naive, fused = cpu_baseline(wl, a.cpu_seconds)
             out["cpu_baseline"] = naive
             out["cpu_baseline_fused"] = fused

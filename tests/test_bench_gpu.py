@@ -58,7 +58,7 @@ def test_one_gpu_line_lists_every_benchmark_configuration():
     assert out["config"]["workload"] == "resnet18_fedavg_k100" and out["scaling"] == "weak"
     names = [w["workload"] for w in out["workloads"]]
     assert names == ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "flat162m_fedavg_k32",
-                     "vitb16_fedasync", "vitb16_fedbuff_k16"]
+                     "vitb16_fedasync", "vitb16_fedbuff_k16", "resnet50_iiadmm_k16", "resnet50_iceadmm_k16"]
     for w in out["workloads"]:
         assert 0 < w["frac"] < 1
         assert abs(w["frac"] - w["algorithmic_bytes_per_launch"] / (w["kernel_avg_ms"] * 1e-3) / 8e12) < 2e-3
