@@ -302,7 +302,7 @@ def cpu_baseline(wl, budget_s):
     return naive_out, fused_out
 
 
-def end_to_end(wl, rounds=4):
+def end_to_end(wl, rounds=4, arrivals=7):
     """aggregate() of the drop-in class as the scheduler calls it: K CPU state dicts in, one CPU
     state dict out (pack + pinned H2D of every client, kernels, D2H).  PCIe-inclusive; reported
     beside `value`, never as `value`."""
@@ -352,7 +352,7 @@ def end_to_end(wl, rounds=4):
     # clients staged as they arrive (aggregator.stage): what is left after the LAST arrival
     ids = list(clients)
     tl = []
-    for _ in range(7):
+    for _ in range(arrivals):
         for c in ids[:-1]:
             agg.stage(c, clients[c])
         torch.cuda.synchronize()
@@ -616,6 +616,11 @@ def main():
                     torch.cuda.empty_cache()
             if not a.no_end_to_end and not is_async:
                 out["end_to_end"] = end_to_end(wl)
+                if name != NORTH_STAR_WORKLOAD:
+                    # the same PCIe-inclusive measurement on the north-star target configuration
+                    e2e = end_to_end(W.WORKLOADS[NORTH_STAR_WORKLOAD], rounds=3, arrivals=3)
+                    e2e["workload"] = NORTH_STAR_WORKLOAD
+                    out["end_to_end_north_star"] = e2e
         if not a.no_cpu_baseline and bench_class(wl) is not AdmmBench:
             naive, fused = cpu_baseline(wl, a.cpu_seconds)
             out["cpu_baseline"] = naive
