@@ -93,6 +93,15 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
     primal_states_curr = primal_states
 
     @property
+    def primal_states_prev(self) -> Dict[Any, Dict[str, torch.Tensor]]:
+        """Every client's message before its last one (the other of its two rows); empty until a
+        second round has run."""
+        with self._lock:
+            if not getattr(self, "_second_round_seen", False):
+                return {}
+            return {cid: self._row_views(self._primal_row(cid, previous=True)) for cid in self._cur}
+
+    @property
     def dual_states(self) -> Dict[Any, Dict[str, torch.Tensor]]:
         with self._lock:
             if self._CLIENT_DUALS:
@@ -186,6 +195,7 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
             self.prim_res = float(norms[0])
             if not first:
                 self.dual_res = float(norms[1])
+            self._second_round_seen = not first
             self.is_first_iter = False
             new = self._layout.views({"f32": host})
             with torch.no_grad():
