@@ -74,6 +74,7 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
         self._res_ws = torch.zeros(N.FA_ADMM_RES_WS, dtype=torch.float64, device=self.device)
         self._norms = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._carry: Optional[torch.Tensor] = None
+        self._prev_same: Dict[Any, bool] = {}         # client id -> its previous primal IS its current one
         self._dl = HostDownloader()
         self._init_lock()
 
@@ -94,12 +95,11 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
 
     @property
     def primal_states_prev(self) -> Dict[Any, Dict[str, torch.Tensor]]:
-        """Every client's message before its last one (the other of its two rows); empty until a
-        second round has run."""
+        """The primal rows as they stood before the last round (empty until a second round has
+        run): a client's other row if it sent a new message in that round, else its current one."""
         with self._lock:
-            if not getattr(self, "_second_round_seen", False):
-                return {}
-            return {cid: self._row_views(self._primal_row(cid, previous=True)) for cid in self._cur}
+            return {cid: self._row_views(self._primal_row(cid, previous=not same))
+                    for cid, same in self._prev_same.items()}
 
     @property
     def dual_states(self) -> Dict[Any, Dict[str, torch.Tensor]]:
@@ -195,7 +195,10 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
             self.prim_res = float(norms[0])
             if not first:
                 self.dual_res = float(norms[1])
-            self._second_round_seen = not first
+            if not first:
+                # :113-122 / :109-118: the snapshot covers every client; one without a new message
+                # this round has previous == current
+                self._prev_same = {cid: cid not in fresh for cid in self._cur}
             self.is_first_iter = False
             new = self._layout.views({"f32": host})
             with torch.no_grad():

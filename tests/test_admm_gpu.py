@@ -119,6 +119,17 @@ def test_admm_classes_keep_the_model_as_the_global_state(cls):
     got["fc.bias"].add_(1.0)                     # the caller may do what it likes with the result
     assert agg.get_parameters()["fc.bias"].numpy().tobytes() == want["fc.bias"].tobytes()
     assert set(agg.dual_states) == {"a", "b"} and agg.dual_states["a"]["fc.bias"].is_cuda
+    for c in ("a", "b"):
+        for k in named:
+            assert agg.primal_states_curr[c][k].cpu().numpy().tobytes() == ora.primal_states_curr[c][k].tobytes()
+            assert agg.primal_states_prev[c][k].cpu().numpy().tobytes() == ora.primal_states_prev[c][k].tobytes()
+    # a client that sends nothing new: its previous primal is its current one afterwards
+    got, want = agg.aggregate({"a": payload(900), "b": None}), ora.aggregate({"a": payload(900), "b": None})
+    for k in want:
+        assert got[k].numpy().tobytes() == want[k].tobytes(), k
+    for c in ("a", "b"):
+        for k in named:
+            assert agg.primal_states_prev[c][k].cpu().numpy().tobytes() == ora.primal_states_prev[c][k].tobytes()
     assert agg.penalty == ora.penalty
 
 
