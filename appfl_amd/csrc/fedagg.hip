@@ -61,7 +61,8 @@ struct ReduceArgs {
     int wt;     // 1: results leave with write-through (sc0 sc1) stores
     int il;     // persistent kernel: 1 = tiles dealt round-robin to the blocks, 0 = contiguous ranges
     int sync;   // persistent kernel, chip-wide write phases: bit 1 = the blocks meet before their
-                // result bursts, bit 0 = and again after the bursts have drained; 0 = no phases
+                // result bursts, bit 0 = and again after the bursts have drained; 0 = no phases;
+                // bits 2-3 = groups of XCDs with staggered phases (0: one group)
     int phase_tiles;       // persistent kernel: tiles per phase (one burst); 0 = all the chip can park
     unsigned* sync_word;   // counter the blocks of this launch meet on (sync != 0); zero between launches
     Hyper h;
@@ -424,6 +425,9 @@ constexpr int kStashMaxTiles = FA_STASH_MAX_TILES;
 #ifndef FA_STASH_REG_BUDGET
 #define FA_STASH_REG_BUDGET 128
 #endif
+#ifndef FA_STASH_ADAM_REGS
+#define FA_STASH_ADAM_REGS 0
+#endif
 constexpr unsigned kPhaseTiles = 4;   // tiles per phase of a vector too long to be parked whole
 constexpr int kStashRegBudget = FA_STASH_REG_BUDGET;   // registers per lane that may hold parked results
 
@@ -441,7 +445,7 @@ struct StashShape {
     // further tiles of a phase whose results wait in registers (16 per result vector and tile):
     // at one wave per SIMD the pipeline leaves about a quarter of the 512 registers unused
     static constexpr int kRegTiles =
-        (OPT == FA_OPT_NONE ? kStashRegBudget : OPT == FA_OPT_AVGM ? kStashRegBudget / 2 : 0) / (16 * kVectors);
+        (OPT == FA_OPT_NONE ? kStashRegBudget : OPT == FA_OPT_AVGM ? kStashRegBudget / 2 : FA_STASH_ADAM_REGS) / (16 * kVectors);
 };
 
 __device__ __forceinline__ void burst_store(float* base, unsigned bytes, unsigned idx, const f4& v) {
@@ -469,6 +473,7 @@ struct GridMeet {
     unsigned* word;
     unsigned arrivals;   // meetings this block has attended
     bool gave_up;
+    unsigned blocks;     // blocks that meet on this word
 };
 
 __device__ __forceinline__ void grid_meet(GridMeet& m) {
@@ -481,7 +486,7 @@ __device__ __forceinline__ void grid_meet(GridMeet& m) {
             // the stragglers costs more than their last reads beside the others' first writes
             // (measured, kernel ms with 0 / 32 / 128 / 192 of 256 blocks not waited for: 650 MB
             // vector 3.68 / 3.63 / 3.62 / 3.67, ResNet-50 K = 64 FedAvg 1.096 / 1.079 / 1.059 / 1.065).
-            const unsigned target = m.arrivals * gridDim.x - gridDim.x / 2;
+            const unsigned target = m.arrivals * m.blocks - m.blocks / 2;
             unsigned polls = 0;
             while ((__hip_atomic_load(m.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kArriveMask) < target) {
                 if (++polls >= kSyncPolls) {
@@ -504,7 +509,7 @@ __device__ __forceinline__ void grid_meet_leave(GridMeet& m, unsigned expected) 
         const unsigned skipped = expected > m.arrivals ? expected - m.arrivals : 0u;
         const unsigned old = __hip_atomic_fetch_add(m.word, kLeaveOne + skipped, __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
-        if ((old >> kLeaveShift) == gridDim.x - 1u)
+        if ((old >> kLeaveShift) == m.blocks - 1u)
             __hip_atomic_store(m.word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -536,8 +541,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
     // Chip-wide write phases (only with round-robin tiles, where all blocks have equal work).
     bool phased = a.sync != 0 && a.il != 0 && a.sync_word != nullptr;
     unsigned P = static_cast<unsigned>(PT);   // tiles per phase: at most what LDS and the spare registers hold
-    GridMeet meet = {a.sync_word, 0u, false};
+    GridMeet meet = {a.sync_word, 0u, false, gridDim.x};
     unsigned meetings = 0;
+    unsigned shift = 0;   // staggered phases: this block's first phase is `shift` tiles shorter
     if (a.il) {
         // Every block gets the same number of equally long tiles where that is possible: the
         // tile is shortened, in steps of one wave-row (64 vectors = 1 KiB; finer steps cost
@@ -569,7 +575,23 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
             P = kPhaseTiles;
         }
         if (most <= P) phased = false;
-        if (phased) meetings = ((most + P - 1) / P) * (((a.sync & 1) ? 1u : 0u) + ((a.sync & 2) ? 1u : 0u));
+        if (phased && (a.sync >> 2) && gridDim.x % 8 == 0) {
+            // Groups of XCDs whose phases are a fraction of a phase apart: while one group drains
+            // its bursts and refills its pipeline, the others keep the memory system reading.
+            // Each group meets on a counter of its own (16 bytes apart in the launch's slot).
+            // Measured against one chip-wide group (kernel time): odd / even XCDs -1.5...-2.4 % on
+            // a 650 MB vector of 32 clients, -1.0...-1.4 % for FedAvgM / FedAvg at 25-47 M
+            // elements x 48-64 clients, +-0.5 % for the two-moment optimizers and for K = 100;
+            // four groups the same or slightly worse; XCDs 0-3 / 4-7 +1...+4 % (slower than one group).
+            const unsigned mode = static_cast<unsigned>(a.sync >> 2) & 3u;   // 1: 2 groups (odd / even XCDs), 2: 4 groups, 3: 2 groups (XCDs 0-3 / 4-7)
+            const unsigned xcd = blockIdx.x % 8u;
+            const unsigned groups = mode == 2u ? 4u : 2u;
+            const unsigned group = mode == 3u ? xcd >> 2 : xcd % groups;
+            meet.word = a.sync_word + 4u * group;
+            meet.blocks = gridDim.x / groups;
+            shift = group * P / groups;
+        }
+        if (phased) meetings = ((most + shift + P - 1) / P) * (((a.sync & 1) ? 1u : 0u) + ((a.sync & 2) ? 1u : 0u));
         if (slot >= total) {
             if (phased) grid_meet_leave(meet, meetings);
             return;
@@ -606,7 +628,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
     // Phased mode: loads are only issued for the tiles of the current phase (S tiles = one
     // burst), so that the pipeline is empty when the burst goes out; `full_*` tell which
     // register set holds an issued, not yet consumed client set.
-    unsigned issue_end = phased ? P : 0xFFFFFFFFu;
+    unsigned issue_end = phased ? P - shift : 0xFFFFFFFFu;
     bool full_a = false, full_b = false, burst_done = false;
 
     auto tile_start = [&](unsigned tile) -> unsigned { return r0 + tile * tstride; };
@@ -644,7 +666,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         }
     };
     auto finish_tile = [&]() {
-        const int j = static_cast<int>(ct % P);
+        const int j = static_cast<int>((ct + shift) % P);
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
             if (a.last && MODE != kOutStepOnly) {
@@ -682,11 +704,13 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
             }
         }
         if (j == static_cast<int>(P) - 1 || ct + 1 == ntiles) {
-            const unsigned first = ct - static_cast<unsigned>(j);
+            const unsigned first = ct - static_cast<unsigned>(j);   // (modular: tile of slot jj = first + jj)
+            // slots below j_lo belong to no tile: the shortened first phase of a staggered block
+            const int j_lo = (ct < P && static_cast<unsigned>(j) >= ct) ? j - static_cast<int>(ct) : 0;
             burst_done = true;
             if (phased && (a.sync & 2)) grid_meet(meet);   // nobody writes before everybody has read
 #pragma unroll 1
-            for (int jj = 0; jj <= j && jj < S; ++jj) {
+            for (int jj = j_lo; jj <= j && jj < S; ++jj) {
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
 #pragma unroll
@@ -698,7 +722,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
             }
 #pragma unroll
             for (int q = 0; q < RT; ++q) {
-                if (S + q <= j) {
+                if (S + q <= j && S + q >= j_lo) {
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
 #pragma unroll
@@ -1118,9 +1142,10 @@ constexpr unsigned kLeanTileVectors = 1u << 20;   // 16 MiB of g
 thread_local int g_write_through = 1;   // fa_tune's nt field: bit 1 set = plain result stores
 thread_local int g_interleave = 1;      // fa_tune's nt field: bit 2 set = contiguous per-block ranges in the persistent kernel
 thread_local int g_phase_tiles = 0;     // fa_tune's nt field, bits 8-12: tiles per phase of the persistent kernel (0: chosen per launch)
-thread_local int g_sync = 2;            // fa_tune's nt field: chip-wide write phases of the persistent kernel -- default: the
-                           // blocks meet before their bursts; bit 4 set = no phases; bit 5 set = they also
-                           // meet after the bursts have drained
+thread_local int g_sync = 2 | (1 << 2);   // fa_tune's nt field: chip-wide write phases of the persistent kernel -- default: the
+                           // blocks meet before their bursts, in two groups (odd / even XCDs) half a phase
+                           // apart; bit 4 set = no phases; bit 5 set = they also meet after the bursts have
+                           // drained; bits 6-7: other groupings
 
 // From this many clients on, the tile-per-block kernel on a long vector takes two vectors per
 // thread instead of one.
@@ -1576,6 +1601,12 @@ int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash) {
     g_write_through = (nt & 2) ? 0 : 1;
     g_interleave = (nt & 4) ? 0 : 1;
     g_sync = (nt & 16) ? 0 : ((nt & 32) ? 3 : 2);
+    if (g_sync) {
+        // bits 6-7: groups of XCDs with staggered phases -- 0: the default (odd / even XCDs),
+        // 1: one group, 2: four groups, 3: XCDs 0-3 / 4-7
+        const int m = (nt >> 6) & 3;
+        g_sync |= (m == 0 ? 1 : m == 1 ? 0 : m) << 2;
+    }
     g_phase_tiles = (nt >> 8) & 31;   // experiment encoding: bits 4-5 of nt = sync mode as is
     g_shape.max_blocks = max_blocks > 0 ? max_blocks : kMaxBlocks;
     g_shape.stash = stash;
