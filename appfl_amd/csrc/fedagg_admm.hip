@@ -129,6 +129,17 @@ __device__ __forceinline__ void admm_fold(const AdmmArgs& a, int k, const Pk<VEC
                                           Pk<VEC>& du, const Pk<VEC>& pv, Pk<VEC>& acc, Pk<VEC>& r,
                                           bool ok, double& prim) {
     const float rho = a.rho[k], c1 = a.c1[k];
+#ifdef FA_ADMM_COPY_ONLY
+    // experiment: the same streams with next to no arithmetic (what the memory system allows)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        acc.e[j] = acc.e[j] + xv.e[j];
+        if (PREV) r.e[j] = r.e[j] + pv.e[j];
+        if (ALG != kII) acc.e[j] = acc.e[j] + du.e[j];
+    }
+    (void)rho; (void)c1; (void)g; (void)ok; (void)prim;
+    return;
+#endif
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const float x = xv.e[j];
