@@ -258,6 +258,31 @@ struct TileRegs {
     Pack<VEC> g[VPT], s[VPT], m[VPT], v[VPT];
 };
 
+// B clients k .. k+B-1 folded into the running step: all their loads first, then the
+// arithmetic in client order.
+template <int VEC, int VPT, int B, bool NT>
+__device__ __forceinline__ void fold_batch(const ReduceArgs& a, int k, const unsigned (&idx)[VPT],
+                                           TileRegs<VEC, VPT>& r) {
+    Pack<VEC> xv[B][VPT];
+#pragma unroll
+    for (int u = 0; u < B; ++u)
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) xv[u][p] = load_stream<VEC, NT>(a.x[k + u], idx[p]);
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+        const float wk = a.w[k + u];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float d = xv[u][p].e[j] - r.g[p].e[j];
+                float wd = d * wk;
+                r.s[p].e[j] = r.s[p].e[j] + wd;
+            }
+        }
+    }
+}
+
 // Folds the K clients of this launch into the step of the vectors idx[0..VPT) and, on the last
 // client chunk, runs the optimizer epilogue and forms g + step.  Everything stays in registers;
 // the caller decides how the results reach memory.
@@ -278,40 +303,19 @@ __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&
             for (int j = 0; j < VEC; ++j) r.s[p].e[j] = 0.0f;
         }
     }
+    // Whole batches of U clients, then the rest in batches of 8 / 4 / 2 / 1: a client count that
+    // is no multiple of U keeps several clients' loads in flight to the end (with one client at
+    // a time, 12 clients at U = 16 ran 20 % slower than 16).
     int k = 0;
-    for (; k + U <= a.K; k += U) {
-        Pack<VEC> xv[U][VPT];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int p = 0; p < VPT; ++p) xv[u][p] = load_stream<VEC, NT>(a.x[k + u], idx[p]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float wk = a.w[k + u];
-#pragma unroll
-            for (int p = 0; p < VPT; ++p) {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    float d = xv[u][p].e[j] - r.g[p].e[j];
-                    float wd = d * wk;
-                    r.s[p].e[j] = r.s[p].e[j] + wd;
-                }
-            }
-        }
+    for (; k + U <= a.K; k += U) fold_batch<VEC, VPT, U, NT>(a, k, idx, r);
+    if constexpr (U > 8) {
+        if (k + 8 <= a.K) { fold_batch<VEC, VPT, 8, NT>(a, k, idx, r); k += 8; }
     }
-    for (; k < a.K; ++k) {
-        const float wk = a.w[k];
-#pragma unroll
-        for (int p = 0; p < VPT; ++p) {
-            Pack<VEC> xv = load_stream<VEC, NT>(a.x[k], idx[p]);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                float d = xv.e[j] - r.g[p].e[j];
-                float wd = d * wk;
-                r.s[p].e[j] = r.s[p].e[j] + wd;
-            }
-        }
+    if constexpr (U > 4) {
+        if (k + 4 <= a.K) { fold_batch<VEC, VPT, 4, NT>(a, k, idx, r); k += 4; }
     }
+    if (k + 2 <= a.K) { fold_batch<VEC, VPT, 2, NT>(a, k, idx, r); k += 2; }
+    if (k < a.K) fold_batch<VEC, VPT, 1, NT>(a, k, idx, r);
     if (!a.last) return;
 #pragma unroll
     for (int p = 0; p < VPT; ++p) {
@@ -1239,15 +1243,16 @@ int launch_reduce_u(const ReduceArgs& a, int unroll, hipStream_t st) {
 }
 
 // Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.  It
-// wins where the client list is long: plain FedAvg from ~32 clients (+2-7 %; below, the
-// tile-per-block kernel is 3-18 % faster), FedAvgM from ~40 (+2-4 %).  Under the two-moment optimizers four result vectors per tile leave LDS room for
+// wins where the client list is long: plain FedAvg and FedAvgM from ~48 clients (+1-3 % over the
+// wide tile-per-block shape below at 48-100 clients; at 32-40 clients that shape is 2-4 % faster,
+// below it more).  Under the two-moment optimizers four result vectors per tile leave LDS room for
 // phases of three tiles only, and many resident waves hide their six state streams better than
 // one wave per SIMD: there the persistent kernel needs 64 clients AND a long vector (measured
 // against the tile-per-block kernel: +4 % at 25 M elements x 64-96 clients, +8-11 % at 87-162 M
 // x 64, but -3 % at 12 M x 64 and -5...-10 % below 56 clients at every length).
 int stash_min_clients(int opt) {
-    if (opt == FA_OPT_NONE) return 32;
-    if (opt == FA_OPT_AVGM) return 40;
+    if (opt == FA_OPT_NONE) return 48;
+    if (opt == FA_OPT_AVGM) return 48;
     return 64;
 }
 int stash_min_tiles_per_cu(int opt) { return opt >= FA_OPT_ADAM ? 20 : 1; }
@@ -1276,6 +1281,17 @@ int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
         // blocks at every size (measured on a 0.58 M-element vector with 32 clients: 21 us with
         // one vector per thread, 40 us with four; 3-5 % at 2 M elements)
         if (!lean && OPT >= FA_OPT_ADAM) vpt = 1;
+        // Plain FedAvg and FedAvgM from ~10 clients: the WIDE shape -- four vectors per thread and
+        // 16 clients ahead, 64 loads of 16 bytes in flight per lane at one wave per SIMD.  With
+        // nothing but streaming to do, bytes in flight per wave beat resident waves: measured
+        // against the shapes above +5-8 % at 16-32 clients on 25-162 M elements, +2-5 % on 2-12 M
+        // elements, +3-5 % for FedAvgM; below 10 clients (or 16 on vectors under 16 M elements)
+        // the shapes above stay ahead.  (Under the two-moment optimizers this shape leaves the
+        // optimizer epilogue nothing to hide behind: 0.47 of peak against 0.70.)
+        if (OPT <= FA_OPT_AVGM && (a.K >= 16 || (a.K >= 10 && a.n >= 4u * kLeanTileVectors))) {
+            vpt = 4;
+            unroll = 16;
+        }
     }
     switch (vpt) {
         case 1: return launch_reduce_u<OPT, 1>(a, unroll, st);

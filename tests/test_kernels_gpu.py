@@ -272,6 +272,34 @@ def test_every_launch_shape_gives_the_same_bits():
         ops.tune()
 
 
+@pytest.mark.parametrize("opt,hp", [("none", {}), ("avgm", HP), ("yogi", HP_YOGI)])
+@pytest.mark.parametrize("K", [3, 10, 15, 17, 23, 31, 47])
+def test_client_counts_that_are_no_multiple_of_the_batch(opt, hp, K):
+    """The client loop folds whole batches of `unroll` clients and then the rest in batches of
+    8 / 4 / 2 / 1: every remainder path, under the widest and the narrowest launch shape, gives
+    the oracle's bits."""
+    from appfl_amd import ops
+    n = 70001
+    code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "yogi": O.OPT_YOGI}[opt]
+    base, xs = make_clients(n, K)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v_ref = np.full_like(base, np.float32(0.0 if opt in ("none", "avgm") else hp["tau"] ** 2))
+    O.reduce_opt(xs, w, g_ref, m_ref, v_ref, code, **hp)
+    dx = [dev(x) for x in xs]
+    try:
+        for vpt, unroll in ((4, 16), (1, 4), (2, 8)):
+            ops.tune(vpt, unroll, 1, 0, 0)
+            g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, v_ref.flat[0] * 0 + (
+                np.float32(0.0 if opt in ("none", "avgm") else hp["tau"] ** 2))))
+            ops.reduce_opt(dx, w, g, m if opt == "yogi" else None, v if opt != "none" else None, opt, **hp)
+            assert_bits(g, g_ref, f"g vpt={vpt} unroll={unroll}")
+            if opt != "none":
+                assert_bits(v, v_ref, f"v vpt={vpt} unroll={unroll}")
+    finally:
+        ops.tune()
+
+
 @pytest.mark.parametrize("opt,hp", [("none", {}), ("avgm", HP), ("adam", HP), ("yogi", HP_YOGI), ("adagrad", HP)])
 @pytest.mark.parametrize("n", [7, 1027, 300007, 4500003])
 @pytest.mark.parametrize("nt", [1, 5], ids=["round_robin", "contiguous"])
@@ -281,9 +309,10 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
     tiles to blocks: same bits as the oracle for the final state, the optional step output and
     the step-only mode."""
     from appfl_amd import ops
-    K = 33 if n > 1000000 else 11
+    K = 49 if n > 1000000 else 11
     if n > 1000000:
         assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
+        assert ops.reduce_kernel_name(33, n, "none") == "reduce_kernel"
         assert ops.reduce_kernel_name(K, n, "adam") == "reduce_kernel"
     code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI,
             "adagrad": O.OPT_ADAGRAD}[opt]

@@ -14,6 +14,28 @@ import torch
 from appfl_amd import ops
 
 
+def time_blocks(fns, reps, batch=1):
+    """Like time_rounds, but every callable runs its `reps` samples in a row (after two warm-up
+    calls of its own): what a server that repeats ONE kernel sees, without whatever the previous
+    shape's traversal order left in the Infinity Cache."""
+    out = []
+    for f in fns:
+        f()
+        f()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(batch):
+                f()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b) / batch)
+        out.append(sorted(ts))
+    return out
+
+
 def time_rounds(fns, reps, batch=1):
     """fns: list of callables; returns per-fn sorted times (ms per call), interleaved round-robin;
     `batch` calls are enqueued back to back between the two events of one sample."""
@@ -40,6 +62,7 @@ def main():
     ap.add_argument("--pad", type=int, default=0, help="extra floats between client rows")
     ap.add_argument("--shapes", default="4,8,1,65536")
     ap.add_argument("--batch", type=int, default=1, help="launches per timed sample (small kernels)")
+    ap.add_argument("--blocks", action="store_true", help="time every shape in a row instead of interleaved")
     a = ap.parse_args()
     shapes = [tuple(int(t) for t in s.split(",")) for s in a.shapes.split(";")]
     hp = dict(lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
@@ -67,7 +90,7 @@ def main():
                 else:
                     ops.reduce_opt(xs, w, g, m, v, opt, **hp)
             return f
-        ts = time_rounds([mk(s) for s in shapes], a.reps, a.batch)
+        ts = (time_blocks if a.blocks else time_rounds)([mk(s) for s in shapes], a.reps, a.batch)
         print(f"== n={n} K={K} opt={opt} client bytes {K*n*4/1e9:.2f} GB", flush=True)
         for s, t in zip(shapes, ts):
             med, best = t[len(t) // 2], t[0]
