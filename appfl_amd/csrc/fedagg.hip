@@ -1245,23 +1245,23 @@ int launch_reduce_u(const ReduceArgs& a, int unroll, hipStream_t st) {
 // Whether a launch over `nvec` 16-byte vectors of K clients goes to the persistent kernel.  It
 // wins where the client list is long: plain FedAvg and FedAvgM from ~48 clients (+1-3 % over the
 // wide tile-per-block shape below at 48-100 clients; at 32-40 clients that shape is 2-4 % faster,
-// below it more).  Under the two-moment optimizers four result vectors per tile leave LDS room for
+// below it more).  Under the two-moment optimizers three result vectors per tile leave LDS room for
 // phases of three tiles only, and many resident waves hide their six state streams better than
-// one wave per SIMD: there the persistent kernel needs 64 clients AND a long vector (measured
-// against the tile-per-block kernel: +4 % at 25 M elements x 64-96 clients, +8-11 % at 87-162 M
-// x 64, but -3 % at 12 M x 64 and -5...-10 % below 56 clients at every length).
-int stash_min_clients(int opt) {
-    if (opt == FA_OPT_NONE) return 48;
-    if (opt == FA_OPT_AVGM) return 48;
-    return 64;
+// one wave per SIMD at short client lists.  With the phases of odd and even XCDs half a phase
+// apart it is ahead from 40 clients on vectors of >= 8 tiles per CU (measured against the
+// tile-per-block kernel: +3 % at 25 M elements x 40-56 clients, +2.5 % / +6 % at 12 M x 48 / 100,
+// +5-6 % at 87 M x 32-48) and from 24 clients on vectors of >= 64 tiles per CU (+6 % at 87 M x
+// 24, +4-5 % at 162 M x 32); below that the tile-per-block kernel wins (25 M x 24-28: +5 %,
+// 12 M x 24-32: +2-8 %, 4.5 M x 32: +8 %).
+bool stash_wins(int opt, int K, uint64_t tiles_per_cu) {
+    if (opt <= FA_OPT_AVGM) return K >= 48 && tiles_per_cu >= 1;
+    return (K >= 40 && tiles_per_cu >= 8) || (K >= 24 && tiles_per_cu >= 64);
 }
-int stash_min_tiles_per_cu(int opt) { return opt >= FA_OPT_ADAM ? 20 : 1; }
 bool takes_stash_path(int opt, int K, uint64_t nvec) {
     if (g_shape.stash < 0) return K > kStashUnroll;
     const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
-    return g_shape.stash > 0 && K >= stash_min_clients(opt) &&
-           nvec >= per_cu * static_cast<uint64_t>(g_shape.stash) &&
-           nvec >= per_cu * static_cast<uint64_t>(stash_min_tiles_per_cu(opt));
+    return g_shape.stash > 0 && nvec >= per_cu * static_cast<uint64_t>(g_shape.stash) &&
+           stash_wins(opt, K, nvec / per_cu);
 }
 
 template <int OPT, int VEC>
