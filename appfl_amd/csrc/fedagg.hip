@@ -962,7 +962,10 @@ __device__ __forceinline__ float async_step(float x, float g, float alpha) {
 
 // The arrival kernels move 2-3 streams in and 1-2 out per element and nothing else; each thread
 // keeps kArrivalVpt vectors of every input stream in flight and results leave write-through.
-constexpr int kArrivalVpt = 4;
+#ifndef FA_ARRIVAL_VPT
+#define FA_ARRIVAL_VPT 4
+#endif
+constexpr int kArrivalVpt = FA_ARRIVAL_VPT;
 
 template <int VEC>
 __device__ __forceinline__ void arrival_indices(unsigned t, unsigned n, unsigned (&idx)[VEC == 4 ? kArrivalVpt : 1],
