@@ -20,7 +20,11 @@ import torch
 from . import _native as N
 from .layout import Layout
 
-PACK_THREADS = 8
+import os
+
+# threads of the native pack / host copy; APPFL_AMD_PACK_THREADS overrides (a server that shares
+# its cores with gRPC workers may want fewer)
+PACK_THREADS = max(1, min(64, int(os.environ.get("APPFL_AMD_PACK_THREADS", "8"))))
 UPLOAD_WINDOW = 32 << 20
 
 
