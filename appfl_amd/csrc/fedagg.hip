@@ -16,6 +16,7 @@
 
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/appfl_amd.h"
@@ -894,21 +895,30 @@ __global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
                 acc[p].e[j] = (a.mode == FA_MIX_SUBTRACT) ? acc[p].e[j] - xw : acc[p].e[j] + xw;
             }
         };
+        // B clients: all their loads, then the arithmetic in client order
+        auto batch = [&](auto tag, int k0) {
+            constexpr int B = decltype(tag)::value;
+            Pack<VEC> xv[B][VPT];
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) xv[u][p] = load_stream<VEC, true>(a.x[k0 + u], idx[p]);
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) fold(xv[u][p], p, a.w[k0 + u]);
+        };
+        // whole batches of U clients, then the rest in batches of 8 / 4 / 2 / 1 (as in fold_tile)
         int k = 0;
-        for (; k + U <= a.K; k += U) {
-            Pack<VEC> xv[U][VPT];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int p = 0; p < VPT; ++p) xv[u][p] = load_stream<VEC, true>(a.x[k + u], idx[p]);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int p = 0; p < VPT; ++p) fold(xv[u][p], p, a.w[k + u]);
+        for (; k + U <= a.K; k += U) batch(std::integral_constant<int, U>{}, k);
+        if constexpr (U > 8) {
+            if (k + 8 <= a.K) { batch(std::integral_constant<int, 8>{}, k); k += 8; }
         }
-        for (; k < a.K; ++k)
-#pragma unroll
-            for (int p = 0; p < VPT; ++p) fold(load_stream<VEC, true>(a.x[k], idx[p]), p, a.w[k]);
+        if constexpr (U > 4) {
+            if (k + 4 <= a.K) { batch(std::integral_constant<int, 4>{}, k); k += 4; }
+        }
+        if (k + 2 <= a.K) { batch(std::integral_constant<int, 2>{}, k); k += 2; }
+        if (k < a.K) batch(std::integral_constant<int, 1>{}, k);
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
             if (!ok[p]) continue;
@@ -1843,6 +1853,8 @@ int fa_weighted_mix(const float* const* x, const double* w, int K, float* g, dou
             a.coeff = static_cast<float>(coeff);
             if (vec) {
                 size_t tiles = (cnt + kThreads * 4 - 1) / (kThreads * 4);
+                // (16 clients ahead at one wave per SIMD, the reduce kernel's wide shape, runs this
+                // kernel at 0.48 of peak against 0.77: its combine modes are run-time branches)
                 hipLaunchKernelGGL((mix_kernel<4, 4, 8>), dim3(static_cast<unsigned>(tiles > size_t(kMaxBlocks) ? kMaxBlocks : tiles)),
                                    dim3(kThreads), 0, st, a);
             } else {

@@ -369,7 +369,7 @@ def test_persistent_stash_kernel_with_client_chunks():
 
 
 @pytest.mark.parametrize("mode,code", [("replace", 0), ("convex", 1), ("subtract", 2), ("convex_one", 3)])
-@pytest.mark.parametrize("n,K", [(5, 1), (4099, 3), (300007, 9), (2051, 131)])
+@pytest.mark.parametrize("n,K", [(5, 1), (4099, 3), (300007, 9), (2051, 131), (70001, 23), (70001, 31), (4099, 16)])
 def test_weighted_mix(mode, code, n, K):
     from appfl_amd import ops
     if mode == "convex_one":
