@@ -1299,8 +1299,9 @@ int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
         // nothing but streaming to do, bytes in flight per wave beat resident waves: measured
         // against the shapes above +5-8 % at 16-32 clients on 25-162 M elements, +2-5 % on 2-12 M
         // elements, +3-5 % for FedAvgM; below 10 clients (or 16 on vectors under 16 M elements)
-        // the shapes above stay ahead.  (Under the two-moment optimizers this shape leaves the
-        // optimizer epilogue nothing to hide behind: 0.47 of peak against 0.70.)
+        // the shapes above stay ahead.  (Under the two-moment optimizers it is within +-1.5 % of the
+        // shapes above at 16-32 clients, and fetching m / v before the client loop instead of after
+        // it changes nothing either: their result writes, not the launch shape, bound them.)
         if (OPT <= FA_OPT_AVGM && (a.K >= 16 || (a.K >= 10 && a.n >= 4u * kLeanTileVectors))) {
             vpt = 4;
             unroll = 16;
