@@ -349,6 +349,41 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
         ops.tune()
 
 
+@pytest.mark.parametrize("opt,hp", [("none", {}), ("adam", HP)])
+def test_phased_persistent_kernel_beside_other_work_on_the_chip(opt, hp):
+    """The persistent kernel's meetings are bounded waits that carry no data: with another
+    stream's kernels holding CUs (so that some of its blocks start late or not together) a
+    phased launch still ends and gives the oracle's bits; the meeting counters are back at zero
+    for the launches that follow."""
+    from appfl_amd import ops
+    n, K = 6_000_004, 49          # ~5.7 tiles per CU: written in two staggered phases
+    assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
+    code = O.OPT_NONE if opt == "none" else O.OPT_ADAM
+    base, xs = make_clients(n, K)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v_ref = np.full_like(base, np.float32(hp["tau"] ** 2 if hp else 0.0))
+    dx = [dev(x) for x in xs]
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    b = torch.empty_like(a)
+    g, m, v = dev(base), dev(m_ref.copy()), dev(v_ref.copy())
+    try:
+        ops.tune(stash=-1)
+        for rnd in range(3):
+            O.reduce_opt(xs, w, g_ref, m_ref, v_ref, code, **hp)
+            with torch.cuda.stream(side):
+                for _ in range(30):
+                    torch.mm(a, a, out=b)
+            ops.reduce_opt(dx, w, g, m if hp else None, v if hp else None, opt, **hp)
+            torch.cuda.synchronize()
+            assert_bits(g, g_ref, f"g round {rnd}")
+            if hp:
+                assert_bits(v, v_ref, f"v round {rnd}")
+    finally:
+        ops.tune()
+
+
 def test_persistent_stash_kernel_with_client_chunks():
     """K > FA_KCHUNK through the persistent kernel: the carry pass parks the partial step."""
     from appfl_amd import ops
