@@ -576,8 +576,13 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
         // ones pay the drain-and-refill too often, in longer ones the blocks drift apart).
         if (a.phase_tiles > 0) {
             if (static_cast<unsigned>(a.phase_tiles) < P) P = static_cast<unsigned>(a.phase_tiles);
-        } else if (most > P && P > kPhaseTiles) {
-            P = kPhaseTiles;
+        } else if (most > P) {
+            // Three or four result vectors per tile (the two-moment optimizers): phases of two
+            // tiles -- with the two staggered groups below, kernel time against phases of three
+            // (all that LDS holds): -2.8 % at 25 M elements x 64 clients, -2.5 % at 25 M x 48,
+            // -1...-2 % at 87 M x 64, -2...-3 % at 162 M x 32, -1 % at 12 M x 64 and 25 M x 100.
+            const unsigned want = NV >= 3 ? 2u : kPhaseTiles;
+            if (P > want) P = want;
         }
         if (most <= P) phased = false;
         if (phased && (a.sync >> 2) && gridDim.x % 8 == 0) {
