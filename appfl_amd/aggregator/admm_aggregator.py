@@ -75,6 +75,7 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
         self._norms = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._carry: Optional[torch.Tensor] = None
         self._prev_same: Dict[Any, bool] = {}         # client id -> its previous primal IS its current one
+        self._staged: Dict[Any, Any] = {}             # client id -> message uploaded on arrival (`stage`)
         self._dl = HostDownloader()
         self._init_lock()
 
@@ -126,6 +127,26 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
             self._dual = torch.zeros((K, self._layout.row_bytes // 4), dtype=torch.float32,
                                      device=self.device)
 
+    def stage(self, client_id, message) -> None:
+        """Optional hook for the scheduler: upload ONE client's message the moment it arrives, so
+        the PCIe transfer overlaps the wait for the other clients.  `aggregate` reuses the staged
+        rows when it later receives the same object for this client.  Only from the second round
+        on (the first round fixes the set of clients); not calling it at all is equally valid."""
+        with self._lock:
+            if not self._rows or client_id not in self._rows or message is None:
+                return
+            for name in self._layout.names:
+                if name not in message["primal"] or (self._CLIENT_DUALS and name not in message["dual"]):
+                    raise KeyError(name)
+            which = 1 - self._cur[client_id] if client_id in self._cur else 0
+            slab, row = self._primal[which], self._rows[client_id]
+            slab.begin_round()
+            slab.upload(row, message["primal"])
+            if self._CLIENT_DUALS:
+                self._dual_slab.begin_round()
+                self._dual_slab.upload(row, message["dual"])
+            self._staged[client_id] = message
+
     def aggregate(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict, None]],
                   **kwargs) -> Dict:
         with self._lock:
@@ -152,17 +173,24 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
                     continue                      # :72 / :67: its last primal, dual and penalty stand
                 which = 1 - self._cur[cid] if cid in self._cur else 0
                 slab, row = self._primal[which], self._rows[cid]
-                if slab not in used:
-                    slab.begin_round()
+                if self._staged.get(cid) is m:
+                    # uploaded on arrival (`stage`): the rows are on their way already
                     used.add(slab)
-                slab.upload(row, m["primal"])
-                if self._CLIENT_DUALS:
-                    if self._dual_slab not in used:
-                        self._dual_slab.begin_round()
+                    if self._CLIENT_DUALS:
                         used.add(self._dual_slab)
-                    self._dual_slab.upload(row, m["dual"])
+                else:
+                    if slab not in used:
+                        slab.begin_round()
+                        used.add(slab)
+                    slab.upload(row, m["primal"])
+                    if self._CLIENT_DUALS:
+                        if self._dual_slab not in used:
+                            self._dual_slab.begin_round()
+                            used.add(self._dual_slab)
+                        self._dual_slab.upload(row, m["dual"])
                 self.penalty[cid] = m["penalty"]
                 fresh.add(cid)
+            self._staged = {}
             first = self.is_first_iter
             prev = None
             if not first:

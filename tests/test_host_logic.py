@@ -35,6 +35,8 @@ def test_argument_checks_without_touching_the_gpu():
     assert lib.fa_reduce_opt(None, None, 0, None, None, None, 0, 0, 0, 0, 0, 0, None, None, None) == -1
     assert lib.fa_tune(3, 8, 1, 0, 4) == -1 and lib.fa_tune(4, 8, 1, 0, 4) == 0
     assert lib.fa_tune(0, 8, 1, 0, 2) == 0          # back to the defaults
+    assert lib.fa_admm_ii(None, None, None, None, 0, 1, None, 0, None, None, None, None) == -1
+    assert lib.fa_admm_ice(None, None, None, None, 3, None, 8, None, None, None, None) == -1
     assert lib.fa_pack_host(None, None, None, None, 0, 1) == -1
     assert lib.fa_pack_host_window(None, None, None, None, 0, 0, 1, 1) == -1
     assert lib.fa_host_copy_fresh(None, None, 8, 1) == -1
