@@ -71,10 +71,12 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * non-temporal client loads, bit 1: plain instead of write-through result stores, bit 2: the
  * persistent kernel gives each block one contiguous range instead of every gridDim-th tile,
  * bit 4: the persistent kernel's blocks do not meet before their result bursts, bit 5: they
- * also meet after the bursts),
+ * also meet after the bursts, bits 6-7: how its blocks are grouped into staggered write phases
+ * -- 0 odd / even XCDs (the default), 1 one chip-wide group, 2 four groups, 3 XCDs 0-3 / 4-7,
+ * bits 8-12: tiles per phase, 0 = chosen per launch),
  * grid cap (<= 0: default) of the tile-per-block kernel, and from how many 16-KiB tiles per CU
- * on a launch with a long client list (FedAvg >= 32, FedAvgM >= 40, two-moment optimizers >= 64
- * clients on long vectors) takes the persistent
+ * a launch with a long client list (FedAvg / FedAvgM >= 48 clients; two-moment optimizers >= 40
+ * clients on vectors of >= 8 tiles per CU, >= 24 on vectors of >= 64) takes the persistent
  * kernel that parks results in LDS and writes them in bursts (stash: 0 never, < 0 always for
  * more than 8 clients, default 2).  Results do not depend on it.
  * Applies to launches made by the calling thread only (thread-local state).
