@@ -234,6 +234,12 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 out.append(1.0 / len(local_models))
         return out
 
+    # bytes per pack / transfer window of a client staged on arrival (measured, time from the last
+    # arrival to the result for ResNet-18 x 100 / ResNet-50 FedAdam x 64: 4 MiB 5.1 / 9.1 ms,
+    # 8 MiB 3.2 / 6.0, 16 MiB 2.6 / 4.8, 32 MiB 2.5 / 5.0; without the pipeline 2.75-3.0 / 5.1-5.4)
+    STAGE_WINDOW = 32 << 20
+    PIPELINE_MIN_ELEMENTS = 4 << 20   # rounds of at least this many weighted elements may be pipelined
+
     def stage(self, client_id, local_model) -> None:
         """Optional hook for the scheduler: pack and upload ONE client's update the moment it
         arrives (sync_scheduler.py:46 is where the reference merely stores it), so the PCIe
@@ -249,7 +255,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._slab.reserve(max(row + 1, int(hint)), preserve=row)
             if row == 0:
                 self._slab.begin_round()
-            self._slab.upload(row, local_model, fill_missing_from=self._flats)
+            # the windows' events are kept: `aggregate` can then start on the head of this row
+            # while its tail still travels, and send results back meanwhile (`_round_pipelined`)
+            self._slab.upload(row, local_model, fill_missing_from=self._flats, window=self.STAGE_WINDOW)
             if self._slab.has_device_sources:
                 # the caller may overwrite its device tensors as soon as this returns
                 self._slab.wait_uploads()
@@ -466,11 +474,80 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     self.compute_steps(local_models)      # user override (may call super())
                 finally:
                     self._staged_for = None
-            self._launch_round(K, self._client_weights(local_models), fused)
+            out = self._round_pipelined(K, self._client_weights(local_models)) if fused else None
+            if out is None:
+                self._launch_round(K, self._client_weights(local_models), fused)
+                out = self._download()
             self.step = {}
-            out = self._download()
             self._sync_model(self.model, out)
             return out
+
+    def _round_pipelined(self, K: int, weights) -> Optional[Dict[str, torch.Tensor]]:
+        """The round after the LAST arrival as a pipeline over the windows of that client's row:
+        every other row has landed (clients staged on arrival), so the fused kernel runs on the
+        stretch of the flat axis a window covers as soon as that window has landed, and the new
+        values of the stretch travel back while the next window is still on its way up -- PCIe
+        carries both directions at once.  Same kernel on the same elements as the plain path
+        (every element is independent), so the same bits.  Returns None when it does not apply
+        (the caller then takes the plain path)."""
+        lay, slab = self._layout, self._slab
+        n_step = lay.count[STEP]
+        if not (self._uploads_pending and self._fold_means and self.device.type == "cuda"
+                and n_step >= self.PIPELINE_MIN_ELEMENTS and not lay.n_f64
+                and hasattr(self._ops, "round_sync") and len(self._row_of) == K and K >= 2):
+            return None
+        rows = self._row_of
+        wins = slab.row_windows.get(rows[-1])
+        if not wins or slab.ready_prefix(rows[:-1]) < K - 1:
+            return None
+        out_f32 = self._dl.lease(torch.float32, lay.n_f32)
+        if out_f32 is None:
+            return None
+        self._uploads_pending = False
+        if getattr(self, "_down_stream", None) is None:
+            self._down_stream = torch.cuda.Stream(device=self.device)
+        compute, down = torch.cuda.current_stream(self.device), self._down_stream
+        self._ensure_moments()
+        ws = None
+        if K > self._ops.kchunk():
+            if self._step_flat is None:
+                self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+            ws = self._step_flat
+        g, ptrs, hyper = self._flats["f32"], self._rows(K, 0), self._hyper()
+        done = 0
+        for a, b, landed in wins:
+            upto = n_step if b >= 4 * n_step else (b // 4) & ~1023      # whole KiB-aligned stretches
+            if upto <= done:
+                continue
+            compute.wait_event(landed)
+            self._ops.round_sync([p + 4 * done for p in ptrs], weights, g[done:],
+                                 None if self._m is None else self._m[done:],
+                                 None if self._v is None else self._v[done:], self._OPT,
+                                 step_ws=None if ws is None else ws[done:], n=upto - done, **hyper)
+            folded = torch.cuda.Event()
+            folded.record(compute)
+            down.wait_event(folded)
+            with torch.cuda.stream(down):
+                out_f32[done:upto].copy_(g[done:upto], non_blocking=True)
+            done = upto
+        slab.end_round()                   # the plain means read every row whole
+        if done < n_step:                  # (a row whose windows stop short of the weighted segment)
+            self._ops.round_sync([p + 4 * done for p in ptrs], weights, g[done:],
+                                 None if self._m is None else self._m[done:],
+                                 None if self._v is None else self._v[done:], self._OPT,
+                                 step_ws=None if ws is None else ws[done:], n=n_step - done, **hyper)
+            out_f32[done:n_step].copy_(g[done:n_step], non_blocking=True)
+        self._launch_means(K)
+        host = {"f32": out_f32, "f64": torch.empty(0, dtype=torch.float64)}
+        if lay.n_f32 > n_step:
+            out_f32[n_step:].copy_(g[n_step:lay.n_f32], non_blocking=True)
+        for key, n in (("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
+            host[key] = self._dl.fetch(self._flats[key], n, wait=False)
+        out = lay.views(host)              # while the last transfers are in flight
+        out.update({k: v.cpu() for k, v in self._extra_state.items()})
+        compute.synchronize()
+        down.synchronize()
+        return out
 
 
     # -- secure-aggregation payloads: fedavg_aggregator.py:171-225 ------------------------------------

@@ -47,6 +47,8 @@ class ClientSlab:
         self.next_slot = 0
         self.last_copy: Optional[torch.cuda.Event] = None
         self.row_event: Dict[int, "torch.cuda.Event"] = {}   # row -> event after its last upload
+        # row -> [(byte_lo, byte_hi, event after that window's transfer)] of its last upload
+        self.row_windows: Dict[int, List] = {}
         self.has_device_sources = False   # the last upload read device tensors of the caller
 
     def reserve(self, rows: int, preserve: int = 0) -> None:
@@ -100,14 +102,16 @@ class ClientSlab:
             self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
 
     def upload(self, k: int, state: Dict[str, torch.Tensor], fill_missing_from=None,
-               on_window=None) -> None:
+               on_window=None, window: Optional[int] = None) -> None:
         """Pack `state` into row k (`on_window(a, b, event)`, if given, is called after the
         transfer of each window [a, b) of the row has been enqueued; only valid when every entry
         of `state` is a host tensor).  Entries of the layout that `state` lacks and that take the
         weighted step are filled from `fill_missing_from` (the global flat vectors by key, or the
         fp32 one alone), which makes
         their difference zero -- the reference skips such a client for that entry
-        (fedavg_aggregator.py:360-361); a missing plain-mean entry raises KeyError (:289)."""
+        (fedavg_aggregator.py:360-361); a missing plain-mean entry raises KeyError (:289).
+        `window`: bytes per pack / transfer window (default UPLOAD_WINDOW); the events of the
+        windows are kept in `row_windows[k]` when every source is a host tensor."""
         lay = self.layout
         host_src: List[int] = []
         host_off: List[int] = []
@@ -154,14 +158,19 @@ class ClientSlab:
             srcs, offs, lens = ((C.c_void_p * T)(*host_src), (C.c_size_t * T)(*host_off),
                                 (C.c_size_t * T)(*host_len))
             pinned, lib = self.pinned[slot], N.load()
-            for a in range(0, self.row_bytes, UPLOAD_WINDOW):
-                b = min(self.row_bytes, a + UPLOAD_WINDOW)
+            step = max(1 << 20, int(window)) if window else UPLOAD_WINDOW
+            record = window is not None and self.on_gpu and not dev_items and not missing
+            wins = []
+            for a in range(0, self.row_bytes, step):
+                b = min(self.row_bytes, a + step)
                 rc = lib.fa_pack_host_window(C.c_void_p(pinned.data_ptr()), srcs, offs, lens, T,
                                              a, b, PACK_THREADS)
                 N.check(rc, "fa_pack_host_window")
                 with self._on_copy_stream():
                     self.slab[k, a:b].copy_(pinned[a:b], non_blocking=True)
-                    landed = self._copy_event() if on_window is not None else None
+                    landed = self._copy_event() if (on_window is not None or record) else None
+                if record:
+                    wins.append((a, b, landed))
                 if on_window is not None:
                     # lets the caller start work on bytes [a, b) of the row once `landed` fires
                     on_window(a, b, landed)
@@ -182,8 +191,11 @@ class ClientSlab:
             ev = self._copy_event()
         self.slot_free[slot] = ev
         self.last_copy = ev
+        self.row_windows.pop(k, None)
         if ev is not None:
             self.row_event[k] = ev
+            if T and record and len(wins) > 1:
+                self.row_windows[k] = wins
         self.has_device_sources = bool(dev_items)
         del keep
 

@@ -217,6 +217,46 @@ def test_staging_on_arrival_gives_the_same_round():
             assert torch.equal(got[k], want[k]), (r, k)
 
 
+@pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedAvgMAggregator", "FedYogiAggregator"])
+def test_round_after_the_last_arrival_runs_as_a_pipeline_over_its_windows(cls, monkeypatch):
+    """Every client staged on arrival and a model long enough: `aggregate` folds the stretch each
+    window of the last client's row covers as it lands and sends it back meanwhile -- the same
+    bits as the oracle's rounds, plain-mean and integer entries included, three rounds in a row
+    (moments carried), and the pipelined path is the one that ran."""
+    import appfl_amd.aggregator as A
+    from appfl_amd.aggregator.fedavg_aggregator import FedAvgAggregator
+    spec = {"w": ((4_600_003,), "f32"), "steps": ((3,), "i64"), "b": ((7, 3), "f32"), "c32": ((5,), "i32")}
+    cfg = dict(S.HP[cls], client_weights_mode="sample_size")
+    agg, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    for a in (agg, ora):
+        for c in range(4):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    taken = []
+    plain = FedAvgAggregator._round_pipelined
+
+    def spy(self, K, weights):
+        out = plain(self, K, weights)
+        taken.append(out is not None)
+        return out
+    monkeypatch.setattr(FedAvgAggregator, "_round_pipelined", spy)
+    monkeypatch.setattr(FedAvgAggregator, "STAGE_WINDOW", 4 << 20)     # several windows per 18 MB row
+    for r, K in enumerate([3, 4, 2]):
+        models = {c: S.make_state(spec, seed=60 * r + c) for c in range(K)}
+        for c, m in models.items():
+            agg.stage(c, m)
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k]), (r, k)
+    assert taken[1:] == [True, True], taken        # (round 0 may start before the rows have landed)
+    # without staging the plain path runs and gives the same bits
+    models = {c: S.make_state(spec, seed=999 + c) for c in range(3)}
+    got, want = agg.aggregate(models), ora.aggregate(models)
+    for k in want:
+        assert golden_util.same_bits(got[k].numpy(), want[k]), k
+    assert taken[-1] is False
+
+
 @pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedAdamAggregator"])
 @pytest.mark.parametrize("landed", ["all_but_last", "half", "one"])
 def test_round_starts_on_the_rows_that_have_landed(cls, landed, monkeypatch):
