@@ -813,6 +813,103 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent kernel with WIDE client batches, for plain FedAvg on very long vectors: one
+// 256-thread block per CU takes every gridDim.x-th tile like reduce_stash_kernel, but folds a tile
+// the way the wide tile-per-block shape does (fold_tile: 16 clients x 4 vectors = 64 loads in
+// flight per lane, no pipelining across tiles), parks the tile's result in LDS and writes ten
+// tiles at a time in the same chip-wide, staggered phases.  Measured against the better of the
+// other two kernels (fraction of peak): 162.5 M elements x 32 clients 0.75 -> 0.85, x 16 0.765 ->
+// 0.80, x 64 0.80 -> 0.83; 120 M x 32 0.75 -> 0.815; 87 M x 16 / 32 / 64 0.77 / 0.75 / 0.79 -> 0.79
+// / 0.81 / 0.82; 325 M x 32 0.79 -> 0.82; level at 65 M elements and at 100 clients, behind below
+// (47 M x 48: 0.76 against 0.79), and far behind under the optimizers, whose epilogue has
+// nothing to hide behind at one wave per SIMD (FedAdam 0.53-0.64 against 0.70-0.75; FedAvgM
+// -1...-3 %).  Phases of ten tiles (all that LDS holds) beat shorter ones here (4 / 6 / 8 / 10
+// tiles on 162.5 M x 32: 0.81 / 0.84 / 0.84 / 0.85).  Only the final form of a launch (weighted
+// step, apply; no step output).
+template <int OPT>
+__global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceArgs a) {
+    constexpr int NV = 1 + (OPT != FA_OPT_NONE) + (OPT >= FA_OPT_ADAM);
+    constexpr int S = (kStashBytes / kStashVecBytes / NV) > kStashMaxTiles ? kStashMaxTiles
+                                                                           : (kStashBytes / kStashVecBytes / NV);
+    constexpr int VPT = kStashVpt;
+    __shared__ f4 stash[S][NV][VPT][kThreads];
+    const unsigned per_round = gridDim.x * kStashTile;
+    const unsigned rounds = (a.n + per_round - 1) / per_round;
+    const unsigned slots = gridDim.x * rounds;
+    const unsigned tlen = (((a.n + slots - 1) / slots) + 63u) & ~63u;
+    const unsigned total = (a.n + tlen - 1) / tlen;
+    unsigned slot = blockIdx.x;
+    if (gridDim.x % 8 == 0) slot = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    if (a.mt.total) mean_tail(a, gridDim.x - 1u - slot);
+    const unsigned most = (total + gridDim.x - 1) / gridDim.x;
+    unsigned P = static_cast<unsigned>(S);
+    bool phased = a.sync != 0 && a.sync_word != nullptr;
+    if (a.phase_tiles > 0 && static_cast<unsigned>(a.phase_tiles) < P) P = static_cast<unsigned>(a.phase_tiles);
+    if (most <= P) phased = false;
+    GridMeet meet = {a.sync_word, 0u, false, gridDim.x};
+    unsigned shift = 0, meetings = 0;
+    if (phased && (a.sync >> 2) && gridDim.x % 8 == 0) {
+        const unsigned mode = static_cast<unsigned>(a.sync >> 2) & 3u;
+        const unsigned xcd = blockIdx.x % 8u;
+        const unsigned groups = mode == 2u ? 4u : 2u;
+        const unsigned group = mode == 3u ? xcd >> 2 : xcd % groups;
+        meet.word = a.sync_word + 4u * group;
+        meet.blocks = gridDim.x / groups;
+        shift = group * P / groups;
+    }
+    if (phased) meetings = (most + shift + P - 1) / P;
+    if (slot >= total) {
+        if (phased) grid_meet_leave(meet, meetings);
+        return;
+    }
+    const unsigned ntiles = (total - slot + gridDim.x - 1) / gridDim.x;
+    const unsigned r0 = slot * tlen, r1 = a.n, tstride = gridDim.x * tlen;
+    const unsigned nbytes = a.n * 16u;
+    float* dst[3] = {a.g, OPT != FA_OPT_NONE ? a.v : nullptr, OPT >= FA_OPT_ADAM ? a.m : nullptr};
+    for (unsigned ct = 0; ct < ntiles; ++ct) {
+        unsigned idx[VPT];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            const unsigned off = p * kThreads + threadIdx.x;
+            const unsigned i = r0 + ct * tstride + off;
+            idx[p] = (off < tlen && i < r1) ? i : r1 - 1;   // idle lanes redo the last vector, never store
+        }
+        TileRegs<4, VPT> r;
+        fold_tile<OPT, 4, VPT, 16, true>(a, idx, r);
+        const int j = static_cast<int>((ct + shift) % P);
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            auto as_f4 = [](const Pack<4>& v) {
+                f4 t;
+                t.x = v.e[0]; t.y = v.e[1]; t.z = v.e[2]; t.w = v.e[3];
+                return t;
+            };
+            stash[j][0][p][threadIdx.x] = as_f4(r.g[p]);
+            if (OPT != FA_OPT_NONE) stash[j][NV > 1 ? 1 : 0][p][threadIdx.x] = as_f4(r.v[p]);
+            if (OPT >= FA_OPT_ADAM) stash[j][NV > 2 ? 2 : 0][p][threadIdx.x] = as_f4(r.m[p]);
+        }
+        if (j == static_cast<int>(P) - 1 || ct + 1 == ntiles) {
+            const unsigned first = ct - static_cast<unsigned>(j);
+            const int j_lo = (ct < P && static_cast<unsigned>(j) >= ct) ? j - static_cast<int>(ct) : 0;
+            if (phased) grid_meet(meet);
+#pragma unroll 1
+            for (int jj = j_lo; jj <= j; ++jj) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c)
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        const unsigned off = p * kThreads + threadIdx.x;
+                        const unsigned i = r0 + (first + jj) * tstride + off;
+                        if (off < tlen && i < r1) burst_store(dst[c], nbytes, i, stash[jj][c][p][threadIdx.x]);
+                    }
+            }
+            if (phased) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain before the next phase's loads
+        }
+    }
+    if (phased) grid_meet_leave(meet, meetings);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Plain mean over clients (entries that bypass the weighted step).
 
 template <typename T>
@@ -1229,6 +1326,26 @@ int launch_stash_m(const ReduceArgs& a0, hipStream_t st) {
 }
 
 template <int OPT>
+int launch_park(const ReduceArgs& a0, hipStream_t st) {
+    ReduceArgs a = a0;
+    a.sync_word = a.sync ? next_sync_word() : nullptr;
+    hipLaunchKernelGGL((reduce_park_kernel<OPT>), dim3(device_cu_count()), dim3(kThreads), 0, st, a);
+    return launch_status();
+}
+
+// Whether a launch takes the wide-batch persistent kernel: plain FedAvg, final form, from 16
+// clients on vectors of at least kParkMinTilesPerCu tiles per CU (fa_tune: stash == -2 forces it
+// at every length, stash == 0 / -1 keep it off).
+constexpr uint64_t kParkMinTilesPerCu = 72;
+bool takes_park_path(int opt, int K, uint64_t nvec, bool final_form) {
+    if (opt != FA_OPT_NONE || !final_form || K < 16 || K > FA_KCHUNK) return false;
+    if (g_shape.stash == -2) return K > kStashUnroll;
+    if (g_shape.stash <= 0) return false;
+    const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
+    return nvec >= per_cu * kParkMinTilesPerCu;
+}
+
+template <int OPT>
 int launch_stash(const ReduceArgs& a, hipStream_t st) {
     if (!a.last) return launch_stash_m<FA_OPT_NONE, kOutStepOnly>(a, st);
     if (!a.apply) return launch_stash_m<FA_OPT_NONE, kOutStepOnly>(a, st);
@@ -1285,6 +1402,9 @@ bool takes_stash_path(int opt, int K, uint64_t nvec) {
 template <int OPT, int VEC>
 int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
     if (VEC == 1) return launch_reduce_s<OPT, 1, 1, 8, true>(a, st);
+    if constexpr (OPT == FA_OPT_NONE) {
+        if (takes_park_path(OPT, a.K, a.n, a.last && a.apply && !a.step_out)) return launch_park<OPT>(a, st);
+    }
     if (takes_stash_path(OPT, a.K, a.n)) return launch_stash<OPT>(a, st);
     int vpt = g_shape.vpt, unroll = g_shape.unroll;
     if (vpt == 0) {
@@ -1624,6 +1744,7 @@ int fa_kchunk(void) { return FA_KCHUNK; }
 const char* fa_reduce_kernel_name(int K, size_t n, int opt) {
     const int k = K > FA_KCHUNK ? FA_KCHUNK : K;
     const uint64_t seg = n > kSegment ? kSegment : n;
+    if (takes_park_path(opt, k, seg / 4, K <= FA_KCHUNK)) return "reduce_park_kernel";
     return takes_stash_path(opt, k, seg / 4) ? "reduce_stash_kernel" : "reduce_kernel";
 }
 

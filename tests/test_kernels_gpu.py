@@ -385,6 +385,68 @@ def test_phased_persistent_kernel_beside_other_work_on_the_chip(opt, hp):
         ops.tune()
 
 
+@pytest.mark.parametrize("n", [7, 1027, 300007, 4500003, 12000004])
+@pytest.mark.parametrize("K", [16, 17, 49, 128])
+@pytest.mark.parametrize("nt", [1, 65, 1025], ids=["default", "one_group", "phases_of_4"])
+def test_wide_persistent_kernel_matches_oracle(n, K, nt):
+    """The wide-batch persistent kernel (plain FedAvg on very long vectors) forced on at every
+    length -- no tile, partial tiles, more tiles per CU than one phase parks -- and with other
+    phase groupings and lengths: the oracle's bits."""
+    from appfl_amd import ops
+    if n > 10_000_000 and K > 17:
+        pytest.skip("host memory")
+    assert ops.reduce_kernel_name(32, 162_500_000, "none") == "reduce_park_kernel"
+    assert ops.reduce_kernel_name(32, 162_500_000, "avgm") == "reduce_kernel"
+    assert ops.reduce_kernel_name(32, 162_500_000, "adam") == "reduce_stash_kernel"
+    assert ops.reduce_kernel_name(15, 162_500_000, "none") == "reduce_kernel"
+    assert ops.reduce_kernel_name(32, 65_000_000, "none") == "reduce_kernel"
+    base, xs = make_clients(n, K)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref = base.copy()
+    O.reduce_opt(xs, w, g_ref, np.zeros_like(base), np.zeros_like(base), O.OPT_NONE)
+    dx = [dev(x) for x in xs]
+    try:
+        ops.tune(nt=nt, stash=-2)
+        assert ops.reduce_kernel_name(K, n, "none") == "reduce_park_kernel"
+        g = dev(base)
+        for _ in range(2):
+            g.copy_(dev(base))
+            ops.reduce_opt(dx, w, g, None, None, "none")
+            assert_bits(g, g_ref, "g")
+    finally:
+        ops.tune()
+
+
+def test_wide_persistent_kernel_after_client_chunks_and_beside_other_work():
+    """K > FA_KCHUNK: the last chunk's launch starts from the carried step.  And with another
+    stream's kernels holding CUs the phased launch still ends with the oracle's bits."""
+    from appfl_amd import ops
+    n, K = 12_000_004, ops.kchunk() + 16
+    base, xs = make_clients(n, 24, spike=False)
+    xs = [xs[k % 24] for k in range(K)]
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref = base.copy()
+    dx24 = [dev(x) for x in xs[:24]]
+    dx = [dx24[k % 24] for k in range(K)]
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    b = torch.empty_like(a)
+    g = dev(base)
+    ws = torch.empty_like(g)
+    try:
+        ops.tune(stash=-2)
+        for rnd in range(2):
+            O.reduce_opt(xs, w, g_ref, np.zeros_like(base), np.zeros_like(base), O.OPT_NONE)
+            with torch.cuda.stream(side):
+                for _ in range(30):
+                    torch.mm(a, a, out=b)
+            ops.reduce_opt(dx, w, g, None, None, "none", step_ws=ws)
+            torch.cuda.synchronize()
+            assert_bits(g, g_ref, f"g round {rnd}")
+    finally:
+        ops.tune()
+
+
 def test_persistent_stash_kernel_with_client_chunks():
     """K > FA_KCHUNK through the persistent kernel: the carry pass parks the partial step."""
     from appfl_amd import ops
@@ -503,9 +565,29 @@ def _round_rows(n_step, counts, K, seed):
     (0, 4, (5, 3, 2)),               # no weighted entries at all
 ])
 def test_round_folds_plain_means_into_the_reduce_launch(opt, hp, n_step, K, counts):
-    from appfl_amd import ops
     if n_step == 0 and opt != "none":
         pytest.skip("nothing to optimise")
+    _check_round(opt, hp, n_step, K, counts)
+
+
+@pytest.mark.parametrize("n_step,K,counts", [
+    (300007, 17, (300, 20, 9)), (2500003, 40, (0, 20, 0)), (2500003, 100, (9000, 53, 5)),
+    (11000003, 16, (0, 20, 0)),      # more tiles per CU than one phase parks
+])
+def test_round_on_the_wide_persistent_kernel(n_step, K, counts):
+    """fa_round with the wide-batch persistent kernel forced on: the plain means ride in its
+    launch as they do in the other kernels'."""
+    from appfl_amd import ops
+    try:
+        ops.tune(stash=-2)
+        assert ops.reduce_kernel_name(K, n_step, "none") == "reduce_park_kernel"
+        _check_round("none", {}, n_step, K, counts)
+    finally:
+        ops.tune()
+
+
+def _check_round(opt, hp, n_step, K, counts):
+    from appfl_amd import ops
     code = {"none": O.OPT_NONE, "adam": O.OPT_ADAM}[opt]
     base, pieces, slab, stride, offs = _round_rows(n_step, counts, K, seed=11)
     w = [(3 + 2 * k) / sum(3 + 2 * j for j in range(K)) for k in range(K)]
