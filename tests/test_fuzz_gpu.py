@@ -1,6 +1,6 @@
 """Seeded random sweep of the C ABI against the C oracle: lengths around tile and vector
 boundaries, client counts around the unroll / chunk limits, misaligned sub-buffers (the scalar
-path), every optimizer, optional outputs, both reduce kernels.  Bit-exact throughout."""
+path), every optimizer, optional outputs, every reduce kernel.  Bit-exact throughout."""
 
 import numpy as np
 import pytest
@@ -38,8 +38,10 @@ def test_random_reduce_rounds(seed):
     try:
         for it in range(10):
             n, K, opt, code, shift, hp, w = _case(rng)
-            forced = int(rng.integers(0, 3))   # 0: default routing, 1: persistent kernel, 2: tile kernel
-            ops.tune(stash={0: 2, 1: -1, 2: 0}[forced])
+            # 0: default routing, 1: persistent kernel, 2: tile kernel, 3: wide-batch persistent
+            # kernel where it applies (plain FedAvg, >= 16 clients), else the persistent kernel
+            forced = int(rng.integers(0, 4))
+            ops.tune(stash={0: 2, 1: -1, 2: 0, 3: -2}[forced])
             with_step = bool(rng.integers(0, 2))
             rounds = int(rng.integers(1, 3))
             base = O.synth_fill(n, 7 + seed, scale=0.05)
