@@ -48,6 +48,8 @@ SIGNATURES = {
     "fa_reduce_opt_static": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p]),
     "fa_reduce_opt_slab": (_i, [_p, _sz, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),
     "fa_reduce_step": (_i, [_p, _p, _i, _p, _p, _sz, _p]),
+    "fa_reduce_step_resume": (_i, [_p, _p, _i, _i, _p, _p, _sz, _p]),
+    "fa_round_resume": (_i, [_p, _p, _i, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _i, _p]),
     "fa_server_opt_step": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _p]),
     "fa_apply_step": (_i, [_p, _p, _sz, _p]),
     "fa_weighted_mix": (_i, [_p, _p, _i, _p, _d, _i, _p, _sz, _p]),

@@ -105,6 +105,11 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._extra_state: Dict[str, torch.Tensor] = {}
         self._dl = HostDownloader()
         self._uploads_pending = False     # `_stage` left the compute stream un-ordered against the uploads
+        # clients staged on arrival whose terms of the weighted step are folded already, under
+        # weights guessed from the configuration: {"w": [...], "event": after the last fold}
+        self._folded: Optional[dict] = None
+        self._folded_round: Optional[dict] = None     # ... as `_stage` found it for the round being aggregated
+        self._fold_flat: Optional[torch.Tensor] = None   # the partial step of the clients folded on arrival
         self._init_lock()
 
     # -- attributes the reference exposes -------------------------------------------------------
@@ -261,7 +266,58 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             if self._slab.has_device_sources:
                 # the caller may overwrite its device tensors as soon as this returns
                 self._slab.wait_uploads()
+            if client_id in self._prestaged:
+                self._folded = {"w": None}          # a client staged twice: rows no longer in arrival order
             self._prestaged[client_id] = (row, local_model)
+            self._fold_on_arrival(row, int(hint))
+
+    FOLD_ON_ARRIVAL = True
+
+    def _guessed_weight(self, client_id, num_clients: int) -> Optional[float]:
+        """The weight `_client_weights` will give this client IF the round turns out to hold
+        exactly the configured `num_clients` clients (all with a known sample size, in
+        `sample_size` mode); `_round_pipelined` checks the guess against the real weights."""
+        if self.client_weights_mode == "sample_size":
+            sizes = getattr(self, "client_sample_size", None) or {}
+            if len(sizes) != num_clients or client_id not in sizes:
+                return None
+            total = sum(sizes.values())
+            return sizes[client_id] / total if total > 0 else None
+        return 1.0 / num_clients
+
+    def _fold_on_arrival(self, row: int, num_clients: int) -> None:
+        """Fold the weighted-step term of the client staged BEFORE this one (its row has landed
+        long ago; the newest row is still travelling) into the partial step, so that the round
+        after the last arrival only has that last client's term left to add.  Same loop over the
+        clients in the same order as the fused kernel, cut between two clients: same bits."""
+        lay = self._layout
+        n_step = lay.count[STEP]
+        if not (self.FOLD_ON_ARRIVAL and self._fold_means and self.device.type == "cuda"
+                and num_clients >= 2 and row >= 1 and n_step >= self.PIPELINE_MIN_ELEMENTS
+                and not lay.n_f64 and hasattr(self._ops, "round_sync")
+                and getattr(type(self).compute_steps, "_appfl_amd_native", False)):
+            return
+        st = self._folded
+        if row == 1:
+            st = self._folded = {"w": [], "event": None}
+        if st is None or st["w"] is None or len(st["w"]) != row - 1 or row > num_clients - 1:
+            return          # out of step with the arrivals (or a round larger than configured): no guess
+        prev = next((cid for cid, (r, _) in self._prestaged.items() if r == row - 1), None)
+        w = None if prev is None else self._guessed_weight(prev, num_clients)
+        if w is None:
+            st["w"] = None
+            return
+        if self._fold_flat is None:
+            self._fold_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+        compute = torch.cuda.current_stream(self.device)
+        compute.wait_event(self._slab.row_event[row - 1])
+        st["w"].append(w)
+        ptrs = [self._slab.row_ptr(r) for r in range(row)]
+        self._ops.reduce_step(ptrs, st["w"], self._flats["f32"], self._fold_flat, n=n_step,
+                              k_done=row - 1)
+        ev = torch.cuda.Event()
+        ev.record(compute)
+        st["event"] = ev
 
     def stage_bytes(self, client_id, model_bytes) -> Dict:
         """`stage` for an update still in wire form (`torch.save` bytes, comm/mpi/serializer.py:46-50,
@@ -314,6 +370,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         if not defer_wait:
             self._slab.end_round()
         self._prestaged = {}
+        self._folded_round, self._folded = self._folded, None
 
     def _hyper(self) -> Dict[str, float]:
         return {}
@@ -514,6 +571,15 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
             ws = self._step_flat
         g, ptrs, hyper = self._flats["f32"], self._rows(K, 0), self._hyper()
+        # the clients folded on arrival: valid when they are this round's first K - 1 clients in
+        # this order and their guessed weights are the real ones to the bit
+        k_done, st = 0, self._folded_round
+        self._folded_round = None
+        if (st and st.get("w") and len(st["w"]) == K - 1 and K - 1 <= self._ops.kchunk()
+                and list(rows[:K - 1]) == list(range(K - 1)) and st["w"] == list(weights[:K - 1])
+                and self._fold_flat is not None):
+            k_done, ws = K - 1, self._fold_flat
+            compute.wait_event(st["event"])
         done = 0
         for a, b, landed in wins:
             upto = n_step if b >= 4 * n_step else (b // 4) & ~1023      # whole KiB-aligned stretches
@@ -523,7 +589,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._ops.round_sync([p + 4 * done for p in ptrs], weights, g[done:],
                                  None if self._m is None else self._m[done:],
                                  None if self._v is None else self._v[done:], self._OPT,
-                                 step_ws=None if ws is None else ws[done:], n=upto - done, **hyper)
+                                 step_ws=None if ws is None else ws[done:], n=upto - done,
+                                 k_done=k_done, **hyper)
             folded = torch.cuda.Event()
             folded.record(compute)
             down.wait_event(folded)
@@ -535,7 +602,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._ops.round_sync([p + 4 * done for p in ptrs], weights, g[done:],
                                  None if self._m is None else self._m[done:],
                                  None if self._v is None else self._v[done:], self._OPT,
-                                 step_ws=None if ws is None else ws[done:], n=n_step - done, **hyper)
+                                 step_ws=None if ws is None else ws[done:], n=n_step - done,
+                                 k_done=k_done, **hyper)
             out_f32[done:n_step].copy_(g[done:n_step], non_blocking=True)
         self._launch_means(K)
         host = {"f32": out_f32, "f64": torch.empty(0, dtype=torch.float64)}

@@ -13,8 +13,12 @@
 #include <stdint.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -1469,6 +1473,7 @@ struct ReduceCall {
     bool* tail_done = nullptr;        // set when a launch took them
     int k_ready = 0;                  // 0 < k_ready < K: only the first k_ready clients' rows have landed;
     hipEvent_t rest_event = nullptr;  // ... the launches that read the others wait for this event
+    int k_done = 0;                   // clients 0..k_done-1 were folded by an earlier call: the carry holds their partial step
 };
 
 // Where the launches of one call cut the client list: every FA_KCHUNK clients, and at
@@ -1483,7 +1488,7 @@ int next_cut(const ReduceCall& c, int k0) {
 // `carry` (step_out when given, else step_ws).
 int reduce_range(const ReduceCall& c, size_t off, size_t len, bool vec, hipStream_t st) {
     float* carry = c.step_out ? c.step_out : c.step_ws;
-    for (int k0 = 0; k0 < c.K;) {
+    for (int k0 = c.k_done; k0 < c.K;) {
         const int k1 = next_cut(c, k0);
         if (k0 > 0 && k0 == c.k_ready && c.rest_event) {
             // the remaining clients' rows are still on their way: everything launched so far
@@ -1533,7 +1538,8 @@ int reduce_dispatch(const ReduceCall& c, hipStream_t st) {
     if (c.opt < FA_OPT_NONE || c.opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
     if (c.opt != FA_OPT_NONE && !c.v) return FA_ERR_INVALID;
     if (c.opt >= FA_OPT_ADAM && !c.m) return FA_ERR_INVALID;
-    if (next_cut(c, 0) < c.K && !c.step_out && !c.step_ws) return FA_ERR_WORKSPACE;
+    if (c.k_done < 0 || c.k_done >= c.K) return FA_ERR_INVALID;
+    if ((c.k_done > 0 || next_cut(c, 0) < c.K) && !c.step_out && !c.step_ws) return FA_ERR_WORKSPACE;
     if (c.n == 0) return FA_OK;
     const void* gp = c.apply ? static_cast<const void*>(c.g) : static_cast<const void*>(c.g_ro);
     bool a4 = aligned_to(gp, 4), a16 = aligned16(gp);
@@ -1730,6 +1736,75 @@ int scratch_for_current_device(float** out) {
     return FA_OK;
 }
 
+// Host threads that copy the parts of a pack job (fa_pack_host).  Started on first use, kept
+// asleep on a condition variable between jobs, never joined (they end with the process); a
+// process forked from one that had a pool starts its own.
+class PackPool {
+public:
+    explicit PackPool(int workers) {
+        try {
+            for (int j = 1; j <= workers; ++j) {
+                std::thread([this, j] { loop(j); }).detach();
+                workers_ = j;
+            }
+        } catch (...) {
+            // the system refused a thread: the pool is the workers that did start
+        }
+    }
+    int workers() const { return workers_; }
+    // fn(0) on the caller, fn(1..parts-1) on the workers; returns when all are done
+    void run(int parts, const std::function<void(int)>& fn) {
+        {
+            std::lock_guard<std::mutex> hold(m_);
+            job_ = &fn;
+            parts_ = parts;
+            pending_ = parts - 1;
+            ++generation_;
+        }
+        wake_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> hold(m_);
+        done_.wait(hold, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(int j) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> hold(m_);
+        for (;;) {
+            wake_.wait(hold, [&] { return generation_ != seen; });
+            seen = generation_;
+            if (j >= parts_ || !job_) continue;
+            const std::function<void(int)>* fn = job_;
+            hold.unlock();
+            (*fn)(j);
+            hold.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    int workers_ = 0;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    const std::function<void(int)>* job_ = nullptr;
+    int parts_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+};
+
+std::mutex g_pack_pool_busy;     // one job at a time
+PackPool* g_pack_pool = nullptr;
+pid_t g_pack_pool_pid = 0;
+
+// Call with g_pack_pool_busy held.
+PackPool* pack_pool() {
+    const pid_t me = getpid();
+    if (!g_pack_pool || g_pack_pool_pid != me) {
+        g_pack_pool = new (std::nothrow) PackPool(15);   // (a parent's pool is left behind: its threads are not ours)
+        g_pack_pool_pid = me;
+    }
+    return g_pack_pool;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1789,13 +1864,13 @@ int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float
     return reduce_dispatch(c, as_stream(stream));
 }
 
-int fa_round(const float* const* x, const double* w, int K, float* g, float* m, float* v,
-             size_t n, int opt, double lr, double beta1, double beta2, double tau, float* step_out,
-             float* step_ws, const fa_mean_segment* means, int n_means, int k_ready,
-             void* rest_event, fa_stream_t stream) {
+static int round_body(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+                      size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                      float* step_out, float* step_ws, const fa_mean_segment* means, int n_means,
+                      int k_ready, void* rest_event, int k_done, fa_stream_t stream) {
     if (n_means < 0 || (n_means > 0 && !means) || !x || K <= 0) return FA_ERR_INVALID;
-    if (k_ready < 0 || k_ready > K) return FA_ERR_INVALID;
-    const bool split = k_ready > 0 && k_ready < K;
+    if (k_ready < 0 || k_ready > K || k_done < 0 || k_done >= K) return FA_ERR_INVALID;
+    const bool split = (k_ready > 0 && k_ready < K) || k_done > 0;
     MeanTail tail;
     memset(&tail, 0, sizeof(tail));
     tail.Kall = static_cast<float>(K);
@@ -1829,13 +1904,14 @@ int fa_round(const float* const* x, const double* w, int K, float* g, float* m, 
         c.tail = &tail;
         c.tail_done = &done;
     }
-    if (split) {
+    if (k_ready > 0 && k_ready < K) {
         c.k_ready = k_ready;
         c.rest_event = static_cast<hipEvent_t>(rest_event);
     }
+    c.k_done = k_done;
     int rc = n > 0 ? reduce_dispatch(c, as_stream(stream)) : FA_OK;
     if (rc != FA_OK || done) return rc;
-    if (split && n == 0 && rest_event) {
+    if (k_ready > 0 && k_ready < K && n == 0 && rest_event) {
         // no weighted entries, so nothing has waited yet: the means below read every client's row
         hipError_t e = hipStreamWaitEvent(as_stream(stream), static_cast<hipEvent_t>(rest_event), 0);
         if (e != hipSuccess) return hip_code(e);
@@ -1857,6 +1933,23 @@ int fa_round(const float* const* x, const double* w, int K, float* g, float* m, 
         if (rc != FA_OK) return rc;
     }
     return FA_OK;
+}
+
+int fa_round(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+             size_t n, int opt, double lr, double beta1, double beta2, double tau, float* step_out,
+             float* step_ws, const fa_mean_segment* means, int n_means, int k_ready,
+             void* rest_event, fa_stream_t stream) {
+    return round_body(x, w, K, g, m, v, n, opt, lr, beta1, beta2, tau, step_out, step_ws, means,
+                      n_means, k_ready, rest_event, 0, stream);
+}
+
+int fa_round_resume(const float* const* x, const double* w, int K, int k_done, float* g, float* m,
+                    float* v, size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                    float* step_ws, const fa_mean_segment* means, int n_means,
+                    fa_stream_t stream) {
+    if (k_done > 0 && !step_ws) return FA_ERR_WORKSPACE;
+    return round_body(x, w, K, g, m, v, n, opt, lr, beta1, beta2, tau, nullptr, step_ws, means,
+                      n_means, 0, nullptr, k_done, stream);
 }
 
 int fa_reduce_apply(const float* const* x, const double* w, int K, float* g, size_t n,
@@ -1895,6 +1988,14 @@ int fa_reduce_step(const float* const* x, const double* w, int K, const float* g
                    size_t n, fa_stream_t stream) {
     ReduceCall c{x, w, K, nullptr, g, nullptr, nullptr, n, FA_OPT_NONE, make_hyper(0, 0, 0, 0),
                  step_out, nullptr, 0};
+    return reduce_dispatch(c, as_stream(stream));
+}
+
+int fa_reduce_step_resume(const float* const* x, const double* w, int K, int k_done,
+                          const float* g, float* step, size_t n, fa_stream_t stream) {
+    ReduceCall c{x, w, K, nullptr, g, nullptr, nullptr, n, FA_OPT_NONE, make_hyper(0, 0, 0, 0),
+                 step, nullptr, 0};
+    c.k_done = k_done;
     return reduce_dispatch(c, as_stream(stream));
 }
 
@@ -2112,11 +2213,24 @@ int fa_pack_host(void* dst, const void* const* src, const size_t* dst_off, const
                        static_cast<const char*>(src[t]) + (s - b), f - s);
         }
     };
-    std::vector<std::thread> pool;
-    pool.reserve(static_cast<size_t>(threads));
-    for (int j = 1; j < threads; ++j) pool.emplace_back(work, j);
+    // The library's sleeping workers take the parts (starting threads per call costs ~0.2 ms,
+    // as much as packing a window of a few MiB); a second caller at the same time, or a call
+    // that wants more parts than there are workers, starts threads of its own.
+    {
+        std::unique_lock<std::mutex> mine(g_pack_pool_busy, std::try_to_lock);
+        if (mine.owns_lock()) {
+            PackPool* pool = pack_pool();
+            if (pool && threads <= pool->workers() + 1) {
+                pool->run(threads, work);
+                return FA_OK;
+            }
+        }
+    }
+    std::vector<std::thread> own;
+    own.reserve(static_cast<size_t>(threads));
+    for (int j = 1; j < threads; ++j) own.emplace_back(work, j);
     work(0);
-    for (auto& th : pool) th.join();
+    for (auto& th : own) th.join();
     return FA_OK;
 }
 

@@ -100,13 +100,15 @@ def round_sync(x: Sequence, w: Sequence[float], g: torch.Tensor,
                opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
                tau: float = 0.0, step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None,
                means: Sequence = (), k_ready: int = 0,
-               rest_event: Optional["torch.cuda.Event"] = None) -> None:
+               rest_event: Optional["torch.cuda.Event"] = None, k_done: int = 0) -> None:
     """One synchronous round over K client rows in as few launches as possible (fa_round):
     `reduce_opt` over ``g[:n]`` plus the plain mean of every ``(row_offset_bytes, out, count)``
     in `means` -- segments found `row_offset_bytes` after ``x[k]`` in every client's row, whose
     means go to ``out[:count]`` (f32 / i64 / i32 by `out`'s dtype).  `k_ready` / `rest_event`:
     only the first `k_ready` clients' rows have landed; they are folded at once, the rest after
-    `rest_event` (recorded behind the remaining transfers) -- needs `step_ws`."""
+    `rest_event` (recorded behind the remaining transfers) -- needs `step_ws`.  `k_done`: the
+    first `k_done` clients were folded into `step_ws` earlier (`reduce_step(..., k_done=)`); the
+    round is finished from there (fa_round_resume)."""
     n = g.numel() if n is None else n
     if len(x) != len(w):
         raise ValueError("one weight per client buffer")
@@ -118,6 +120,16 @@ def round_sync(x: Sequence, w: Sequence[float], g: torch.Tensor,
         if out.numel() < count:
             raise ValueError("mean output shorter than its segment")
         segs[i] = N.MeanSegment(int(off), _dev(out), int(count), _MEAN_DT[out.dtype])
+    if k_done:
+        if k_ready:
+            raise ValueError("k_ready and k_done exclude each other")
+        rc = N.load().fa_round_resume(_check_rows(x, n, torch.float32), N.double_array([float(t) for t in w]),
+                                      len(x), int(k_done), _dev(g, torch.float32), _dev(m, torch.float32),
+                                      _dev(v, torch.float32), n, OPT_CODES[opt], float(lr), float(beta1),
+                                      float(beta2), float(tau), _dev(step_ws, torch.float32),
+                                      segs, len(means), _stream(g))
+        N.check(rc, "fa_round_resume")
+        return
     rc = N.load().fa_round(_check_rows(x, n, torch.float32), N.double_array([float(t) for t in w]),
                            len(x), _dev(g, torch.float32), _dev(m, torch.float32),
                            _dev(v, torch.float32), n, OPT_CODES[opt], float(lr), float(beta1),
@@ -144,10 +156,22 @@ def reduce_opt_slab(slab: torch.Tensor, stride: int, w: Sequence[float], g: torc
     N.check(rc, "fa_reduce_opt_slab")
 
 
-def reduce_step(x, w, g, step_out, n: Optional[int] = None) -> None:
+def reduce_step(x, w, g, step_out, n: Optional[int] = None, k_done: int = 0) -> None:
+    """Weighted step alone into `step_out` (fa_reduce_step).  `k_done` > 0: `step_out` holds the
+    partial step of the first `k_done` clients already; the others are folded onto it
+    (fa_reduce_step_resume, fp32 only)."""
     n = g.numel() if n is None else n
     if step_out.numel() < n:
         raise ValueError("step_out shorter than n")
+    if k_done:
+        if g.dtype != torch.float32:
+            raise NotImplementedError("resumed steps are fp32 only")
+        rc = N.load().fa_reduce_step_resume(_check_rows(x, n, torch.float32),
+                                            N.double_array([float(t) for t in w]), len(x), int(k_done),
+                                            _dev(g, torch.float32), _dev(step_out, torch.float32), n,
+                                            _stream(g))
+        N.check(rc, "fa_reduce_step_resume")
+        return
     fn, dt = _float_entry("fa_reduce_step", g)
     rc = fn(_check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x),
             _dev(g, dt), _dev(step_out, dt), n, _stream(g))

@@ -336,7 +336,8 @@ def end_to_end(wl, rounds=4, arrivals=7):
     clients = {k: state(1000 + k) for k in range(K)}
     nbytes = sum(t.numel() * t.element_size() for t in clients[0].values())
     del base, buf
-    agg = getattr(A, wl["cls"])(None, dict(W.EXAMPLE_CONFIGS[wl["cls"]]), None)
+    # ServerAgent copies the number of clients into the aggregator's configuration (agent/server.py:652-662)
+    agg = getattr(A, wl["cls"])(None, dict(W.EXAMPLE_CONFIGS[wl["cls"]], num_clients=K), None)
     ts = []
     for _ in range(rounds):
         torch.cuda.synchronize()

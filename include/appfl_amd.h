@@ -182,6 +182,29 @@ int fa_reduce_step(const float* const* x, const double* w, int K, const float* g
                    float* step_out, size_t n, fa_stream_t stream);
 
 /*
+ * The weighted step of a round folded a few clients at a time, as they arrive, and the round
+ * finished from there.  The reference folds all clients inside aggregate()
+ * (fedavg_aggregator.py:359-368, after SyncScheduler.schedule has collected them,
+ * scheduler/sync_scheduler.py:46-76); a server that knows the round's weights beforehand can
+ * spend the wait for the stragglers on the early clients' terms instead.  The arithmetic is
+ * the loop of fa_reduce_opt cut between two clients (the partial step is an fp32 value the loop
+ * holds anyway), so the results are the same bits as one call over all K clients.
+ *
+ * fa_reduce_step_resume: `step` holds the partial step of clients 0..k_done-1 (ignored and
+ * overwritten when k_done == 0); on return it holds that of clients 0..K-1.  x, w: all K entries
+ * (those before k_done are not read from the device).  g is only read.
+ * fa_round_resume: fa_round whose weighted step starts from `step_ws` = the partial step of
+ * clients 0..k_done-1 (0 <= k_done < K; k_done == 0: fa_round without k_ready); the plain means
+ * still read all K rows.
+ */
+int fa_reduce_step_resume(const float* const* x, const double* w, int K, int k_done,
+                          const float* g, float* step, size_t n, fa_stream_t stream);
+int fa_round_resume(const float* const* x, const double* w, int K, int k_done, float* g, float* m,
+                    float* v, size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                    float* step_ws, const fa_mean_segment* means, int n_means,
+                    fa_stream_t stream);
+
+/*
  * Server-optimizer epilogue alone, for callers that computed the averaged step themselves:
  * step (in: averaged pseudo-gradient, out: optimizer step), m, v updated in place with the
  * formulas of fa_reduce_opt.  Replaces the part of the subclass compute_steps bodies after

@@ -257,6 +257,73 @@ def test_round_after_the_last_arrival_runs_as_a_pipeline_over_its_windows(cls, m
     assert taken[-1] is False
 
 
+@pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedAvgMAggregator", "FedYogiAggregator"])
+@pytest.mark.parametrize("mode", ["equal", "sample_size"])
+def test_clients_staged_on_arrival_are_folded_while_the_others_are_awaited(cls, mode, monkeypatch):
+    """With `num_clients` configured, `stage` folds each earlier client's term of the weighted
+    step as the next one arrives; `aggregate` then only adds the last client's.  The oracle's
+    bits, and the resumed path is the one that ran -- unless the round is not the configured one
+    (fewer clients, another order, other weights), in which case the guess is dropped and the
+    plain path gives the same bits."""
+    import appfl_amd.aggregator as A
+    from appfl_amd import ops
+    from appfl_amd.aggregator.fedavg_aggregator import FedAvgAggregator
+    spec = {"w": ((4_600_003,), "f32"), "steps": ((3,), "i64"), "b": ((7, 3), "f32"), "c32": ((5,), "i32")}
+    K = 5
+    cfg = dict(S.HP[cls], client_weights_mode=mode, num_clients=K)
+    agg, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    for a in (agg, ora):
+        for c in range(K):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    resumed = []
+    plain = ops.round_sync
+
+    def spy(*args, **kw):
+        resumed.append(kw.get("k_done", 0))
+        return plain(*args, **kw)
+    monkeypatch.setattr(ops, "round_sync", spy)
+    monkeypatch.setattr(FedAvgAggregator, "STAGE_WINDOW", 4 << 20)     # several windows per 18 MB row
+
+    def one_round(r, ids, order=None):
+        models = {c: S.make_state(spec, seed=70 * r + c) for c in ids}
+        for c, m in models.items():
+            agg.stage(c, m)
+            torch.cuda.synchronize()     # the row has landed before the next client "arrives"
+        if order is not None:
+            models = {c: models[c] for c in order}
+        del resumed[:]
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k]), (r, k)
+        return list(resumed)
+
+    for r in range(3):
+        calls = one_round(r, range(K))
+        assert calls and all(k == K - 1 for k in calls), (r, calls)
+    # one client short of the configured round: every guessed weight is wrong
+    calls = one_round(3, range(K - 1))
+    assert calls and all(k == 0 for k in calls), calls
+    # the scheduler hands the clients over in another order than they arrived
+    calls = one_round(4, range(K), order=[1, 0, 2, 3, 4])
+    assert all(k == 0 for k in calls), calls
+    # and the configured round again
+    calls = one_round(5, range(K))
+    assert calls and all(k == K - 1 for k in calls), calls
+    if mode == "sample_size":
+        # a sample size changes after the early clients were folded
+        models = {c: S.make_state(spec, seed=900 + c) for c in range(K)}
+        for c, m in models.items():
+            agg.stage(c, m)
+        for a in (agg, ora):
+            a.set_client_sample_size(0, 40)
+        del resumed[:]
+        got, want = agg.aggregate(models), ora.aggregate(models)
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k]), k
+        assert all(k == 0 for k in resumed), resumed
+
+
 @pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedAdamAggregator"])
 @pytest.mark.parametrize("landed", ["all_but_last", "half", "one"])
 def test_round_starts_on_the_rows_that_have_landed(cls, landed, monkeypatch):

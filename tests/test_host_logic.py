@@ -63,6 +63,49 @@ def test_pack_host_matches_numpy():
         assert np.array_equal(dst, want), threads
 
 
+def test_pack_host_worker_pool_many_jobs_callers_and_a_forked_child():
+    """The pack jobs run on the library's sleeping workers: job after job, more parts than
+    workers (threads of its own), several callers at once (the late ones start their own
+    threads), and a forked child (which has none of the parent's workers) all copy the same
+    bytes."""
+    import os
+    import threading
+    rng = np.random.default_rng(1)
+    sizes = [2 * 1024 * 1024 + 3, 1, 0, 1024 * 1024 + 11, 5 * 1024 * 1024]
+    srcs = [rng.integers(0, 255, s, dtype=np.uint8) for s in sizes]
+    offs, pos = [], 0
+    for s in sizes:
+        offs.append(pos)
+        pos += s + 9
+    want = np.zeros(pos, np.uint8)
+    for a, o in zip(srcs, offs):
+        want[o:o + a.size] = a
+    T = len(sizes)
+
+    def run(threads):
+        dst = np.zeros(pos, np.uint8)
+        rc = N.load().fa_pack_host(
+            C.c_void_p(dst.ctypes.data), (C.c_void_p * T)(*[a.ctypes.data if a.size else None for a in srcs]),
+            (C.c_size_t * T)(*offs), (C.c_size_t * T)(*sizes), T, threads)
+        return rc == 0 and np.array_equal(dst, want)
+
+    for threads in (8, 2, 16, 17, 64, 8, 8):
+        assert run(threads), threads
+    bad = []
+    callers = [threading.Thread(target=lambda: bad.extend(t for t in (8, 3, 8, 16) if not run(t)))
+               for _ in range(4)]
+    for t in callers:
+        t.start()
+    for t in callers:
+        t.join()
+    assert not bad
+    pid = os.fork()
+    if pid == 0:
+        os._exit(0 if run(8) and run(8) else 1)
+    assert os.waitpid(pid, 0)[1] == 0
+    assert run(8)
+
+
 def test_layout_classes_offsets_and_rows():
     model = S.ToyModel()
     state = model.state_dict()

@@ -675,3 +675,56 @@ def test_round_split_where_the_uploads_have_landed(opt, hp, n_step, K, k_ready):
         assert_bits(v, v_ref, "v")
     for j, name in enumerate(("mean f32", "mean i64", "mean i32")):
         assert_bits(outs[j], wants[j], name)
+
+
+@pytest.mark.parametrize("opt,hp", [("none", {}), ("avgm", HP), ("adam", HP)])
+@pytest.mark.parametrize("n_step,K,cuts", [
+    (4099, 3, (1, 2)), (4099, 100, (1, 2, 3, 50, 99)), (1027, 128, (127,)), (300007, 70, (10, 69)),
+    (2500003, 40, (1, 39)),
+    (4099, 200, (1, 128, 199)), (4099, 200, (60, 130)),   # beside the cuts every FA_KCHUNK clients
+    (3, 5, (4,)),                                         # scalar kernel
+])
+def test_round_resumed_from_a_partial_step(opt, hp, n_step, K, cuts):
+    """fa_reduce_step_resume + fa_round_resume: the clients folded a few at a time (as they
+    arrive), the round finished from the partial step -- the bits of one launch over all K."""
+    from appfl_amd import ops
+    code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM}[opt]
+    counts = (5, 3, 2)
+    base, pieces, slab, stride, offs = _round_rows(n_step, counts, K, seed=31)
+    w = [(3 + 2 * k) / sum(3 + 2 * j for j in range(K)) for k in range(K)]
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v0 = np.float32(HP["tau"] ** 2 if opt == "adam" else 0.0)
+    v_ref = np.full_like(base, v0)
+    O.reduce_opt([p[0] for p in pieces], w, g_ref, m_ref, v_ref, code, **hp)
+    wants = []
+    for j, dt in enumerate((np.float32, np.int64, np.int32)):
+        want = np.zeros(counts[j], dt)
+        O.mean([p[1 + j] for p in pieces], want)
+        wants.append(want)
+    g = dev(base)
+    m, v = torch.zeros_like(g), torch.full_like(g, float(v0))
+    outs = [torch.full((c,), -77, dtype=t, device="cuda")
+            for c, t in zip(counts, (torch.float32, torch.int64, torch.int32))]
+    rows = [slab.data_ptr() + k * stride for k in range(K)]
+    means = [(offs[j], outs[j], counts[j]) for j in range(3)]
+    step = torch.full((n_step,), 123.0, device="cuda")     # stale contents: the first fold overwrites
+    with pytest.raises(Exception):       # resuming needs the partial step
+        ops.round_sync(rows, w, g, n=n_step, k_done=cuts[0])
+    with pytest.raises(Exception):       # at least one client is left to fold
+        ops.round_sync(rows, w, g, step_ws=step, n=n_step, k_done=K)
+    done = 0
+    for cut in cuts:
+        # later rows may not have landed yet: only rows [done, cut) are read
+        ops.reduce_step(rows[:cut], w[:cut], g, step, n=n_step, k_done=done) if done else \
+            ops.reduce_step(rows[:cut], w[:cut], g, step, n=n_step)
+        done = cut
+    ops.round_sync(rows, w, g, m if opt == "adam" else None, v if opt != "none" else None, opt,
+                   step_ws=step, n=n_step, means=means, k_done=done, **hp)
+    torch.cuda.synchronize()
+    assert_bits(g, g_ref, "g")
+    if opt != "none":
+        assert_bits(v, v_ref, "v")
+    if opt == "adam":
+        assert_bits(m, m_ref, "m")
+    for j, name in enumerate(("mean f32", "mean i64", "mean i32")):
+        assert_bits(outs[j], wants[j], name)
