@@ -15,6 +15,8 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -1736,12 +1738,17 @@ int scratch_for_current_device(float** out) {
     return FA_OK;
 }
 
-// Host threads that copy the parts of a pack job (fa_pack_host).  Started on first use, kept
-// asleep on a condition variable between jobs, never joined (they end with the process); a
-// process forked from one that had a pool starts its own.
+// Host threads that copy the parts of a pack job (fa_pack_host).  Started on first use, never
+// joined (they end with the process); a process forked from one that had a pool starts its own.
+// Between jobs a worker first spins on a ticket of its own for a short while -- the windows of
+// one upload follow each other within microseconds, and waking a sleeping thread costs more
+// than copying its share of a small window -- and then sleeps on a condition variable.
 class PackPool {
 public:
+    static constexpr int kMaxWorkers = 15;
+
     explicit PackPool(int workers) {
+        if (workers > kMaxWorkers) workers = kMaxWorkers;
         try {
             for (int j = 1; j <= workers; ++j) {
                 std::thread([this, j] { loop(j); }).detach();
@@ -1752,43 +1759,65 @@ public:
         }
     }
     int workers() const { return workers_; }
-    // fn(0) on the caller, fn(1..parts-1) on the workers; returns when all are done
+    // fn(0) on the caller, fn(1..parts-1) on the workers; returns when all are done.  One job
+    // at a time (the caller holds g_pack_pool_busy).
     void run(int parts, const std::function<void(int)>& fn) {
-        {
-            std::lock_guard<std::mutex> hold(m_);
-            job_ = &fn;
-            parts_ = parts;
-            pending_ = parts - 1;
-            ++generation_;
-        }
+        job_ = &fn;
+        pending_.store(parts - 1, std::memory_order_relaxed);
+        const uint64_t ticket = ++issued_;
+        for (int j = 1; j < parts; ++j) slot_[j].ticket.store(ticket, std::memory_order_seq_cst);
+        { std::lock_guard<std::mutex> hold(m_); }    // a worker between its last look and its sleep gets there first
         wake_.notify_all();
         fn(0);
-        std::unique_lock<std::mutex> hold(m_);
-        done_.wait(hold, [this] { return pending_ == 0; });
+        if (!spin_until([this] { return pending_.load(std::memory_order_acquire) == 0; }, kCallerSpinUs)) {
+            std::unique_lock<std::mutex> hold(m_);
+            done_.wait(hold, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
         job_ = nullptr;
     }
 
 private:
+    static constexpr int kWorkerSpinUs = 150, kCallerSpinUs = 2000;
+    struct alignas(64) Slot {
+        std::atomic<uint64_t> ticket{0};   // number of the last job handed to this worker
+    };
+
+    template <typename Pred>
+    static bool spin_until(Pred ready, int micros) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(micros);
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                if (ready()) return true;
+                __builtin_ia32_pause();
+            }
+            if (std::chrono::steady_clock::now() >= until) return ready();
+        }
+    }
+
     void loop(int j) {
         uint64_t seen = 0;
-        std::unique_lock<std::mutex> hold(m_);
+        auto handed = [&] { return slot_[j].ticket.load(std::memory_order_seq_cst) != seen; };
         for (;;) {
-            wake_.wait(hold, [&] { return generation_ != seen; });
-            seen = generation_;
-            if (j >= parts_ || !job_) continue;
-            const std::function<void(int)>* fn = job_;
-            hold.unlock();
-            (*fn)(j);
-            hold.lock();
-            if (--pending_ == 0) done_.notify_one();
+            if (!spin_until(handed, kWorkerSpinUs)) {
+                std::unique_lock<std::mutex> hold(m_);
+                wake_.wait(hold, handed);
+            }
+            seen = slot_[j].ticket.load(std::memory_order_seq_cst);
+            // job_ was written before the ticket and stays put until every part has reported
+            (*job_)(j);
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                { std::lock_guard<std::mutex> hold(m_); }
+                done_.notify_one();
+            }
         }
     }
     int workers_ = 0;
     std::mutex m_;
     std::condition_variable wake_, done_;
     const std::function<void(int)>* job_ = nullptr;
-    int parts_ = 0, pending_ = 0;
-    uint64_t generation_ = 0;
+    uint64_t issued_ = 0;
+    std::atomic<int> pending_{0};
+    Slot slot_[kMaxWorkers + 1];
 };
 
 std::mutex g_pack_pool_busy;     // one job at a time

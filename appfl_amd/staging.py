@@ -24,7 +24,17 @@ import os
 
 # threads of the native pack / host copy; APPFL_AMD_PACK_THREADS overrides (a server that shares
 # its cores with gRPC workers may want fewer)
-PACK_THREADS = max(1, min(64, int(os.environ.get("APPFL_AMD_PACK_THREADS", "8"))))
+# (default: 8, or half the CPUs this process may run on where those are fewer than 16 -- the
+# pack workers spin briefly between windows, which needs cores of their own)
+def _default_pack_threads() -> int:
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    return max(1, min(8, cpus // 2))
+
+
+PACK_THREADS = max(1, min(64, int(os.environ.get("APPFL_AMD_PACK_THREADS", "0")) or _default_pack_threads()))
 UPLOAD_WINDOW = 32 << 20
 
 
