@@ -575,7 +575,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         # this order and their guessed weights are the real ones to the bit
         k_done, st = 0, self._folded_round
         self._folded_round = None
-        if (st and st.get("w") and len(st["w"]) == K - 1 and K - 1 <= self._ops.kchunk()
+        if (st and st.get("w") and len(st["w"]) == K - 1
                 and list(rows[:K - 1]) == list(range(K - 1)) and st["w"] == list(weights[:K - 1])
                 and self._fold_flat is not None):
             k_done, ws = K - 1, self._fold_flat

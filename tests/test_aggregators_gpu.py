@@ -324,6 +324,38 @@ def test_clients_staged_on_arrival_are_folded_while_the_others_are_awaited(cls, 
         assert all(k == 0 for k in resumed), resumed
 
 
+def test_more_clients_folded_on_arrival_than_one_launch_takes(monkeypatch):
+    """131 clients staged on arrival: the partial step of the first 130 (more than one launch
+    folds) is what the round after the last arrival starts from."""
+    import appfl_amd.aggregator as A
+    from appfl_amd import ops
+    from appfl_amd.aggregator.fedavg_aggregator import FedAvgAggregator
+    spec = {"w": ((1_100_003,), "f32"), "steps": ((3,), "i64")}
+    K = ops.kchunk() + 3
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="equal", num_clients=K)
+    agg, ora = A.FedAdamAggregator(None, cfg, None), OA.ORACLES["FedAdamAggregator"](None, cfg, None)
+    resumed = []
+    plain = ops.round_sync
+
+    def spy(*args, **kw):
+        resumed.append(kw.get("k_done", 0))
+        return plain(*args, **kw)
+    monkeypatch.setattr(ops, "round_sync", spy)
+    monkeypatch.setattr(FedAvgAggregator, "STAGE_WINDOW", 1 << 20)
+    monkeypatch.setattr(FedAvgAggregator, "PIPELINE_MIN_ELEMENTS", 1 << 20)
+    for r in range(2):
+        models = {c: S.make_state(spec, seed=200 * r + c) for c in range(K)}
+        for c, m in models.items():
+            agg.stage(c, m)
+        torch.cuda.synchronize()
+        del resumed[:]
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), want[k]), (r, k)
+        assert resumed and all(k == K - 1 for k in resumed), (r, resumed)
+
+
 @pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedAdamAggregator"])
 @pytest.mark.parametrize("landed", ["all_but_last", "half", "one"])
 def test_round_starts_on_the_rows_that_have_landed(cls, landed, monkeypatch):
