@@ -32,7 +32,11 @@ namespace {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 1 << 16;   // grid cap; larger inputs are walked grid-stride
+// Grid cap; larger inputs are walked grid-stride.  It covers a whole launch segment (2^29
+// elements) at one 4-KiB tile per block: with a cap of 2^16 a resident block of a long vector
+// hopped between stretches 256 MiB apart in every row, which cost 5-7 % at 2-8 clients on
+// 162.5 M elements (fraction of peak 0.745 / 0.705 / 0.674 -> 0.78 / 0.75 / 0.72).
+constexpr int kMaxBlocks = 1 << 20;
 
 struct Hyper {
     float lr, b1, omb1, b2, omb2, tau;
@@ -829,7 +833,8 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
 // / 0.81 / 0.82; 325 M x 32 0.79 -> 0.82; level at 65 M elements and at 100 clients, behind below
 // (47 M x 48: 0.76 against 0.79), and far behind under the optimizers, whose epilogue has
 // nothing to hide behind at one wave per SIMD (FedAdam 0.53-0.64 against 0.70-0.75; FedAvgM
-// -1...-3 %).  Phases of ten tiles (all that LDS holds) beat shorter ones here (4 / 6 / 8 / 10
+// -1...-3 %).  Short client lists gain as much (8 / 12 clients on 162.5 M: 0.72 / 0.75 -> 0.77 /
+// 0.80).  Phases of ten tiles (all that LDS holds) beat shorter ones here (4 / 6 / 8 / 10
 // tiles on 162.5 M x 32: 0.81 / 0.84 / 0.84 / 0.85).  Only the final form of a launch (weighted
 // step, apply; no step output).
 template <int OPT>
@@ -1339,14 +1344,18 @@ int launch_park(const ReduceArgs& a0, hipStream_t st) {
     return launch_status();
 }
 
-// Whether a launch takes the wide-batch persistent kernel: plain FedAvg, final form, from 16
+// Whether a launch takes the wide-batch persistent kernel: plain FedAvg, final form, from 6
 // clients on vectors of at least kParkMinTilesPerCu tiles per CU (fa_tune: stash == -2 forces it
-// at every length, stash == 0 / -1 keep it off).
+// at every length and client count, stash == 0 / -1 keep it off).  Against the tile-per-block
+// kernel on 162.5 M elements (fraction of peak): 2 / 4 clients 0.78 / 0.75 vs 0.73 / 0.74 (behind),
+// 5 / 6 / 7 / 8 / 12 / 14 clients 0.755 / 0.73 / 0.73 / 0.72 / 0.75 / 0.74 -> 0.76 / 0.755 / 0.76 /
+// 0.77 / 0.80 / 0.80; the same at 87 M, 120 M and 325 M elements; +2 % at 75 M.
 constexpr uint64_t kParkMinTilesPerCu = 72;
+constexpr int kParkMinClients = 6;
 bool takes_park_path(int opt, int K, uint64_t nvec, bool final_form) {
-    if (opt != FA_OPT_NONE || !final_form || K < 16 || K > FA_KCHUNK) return false;
-    if (g_shape.stash == -2) return K > kStashUnroll;
-    if (g_shape.stash <= 0) return false;
+    if (opt != FA_OPT_NONE || !final_form || K > FA_KCHUNK) return false;
+    if (g_shape.stash == -2) return true;
+    if (g_shape.stash <= 0 || K < kParkMinClients) return false;
     const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
     return nvec >= per_cu * kParkMinTilesPerCu;
 }

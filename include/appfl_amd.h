@@ -78,10 +78,10 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * a launch with a long client list (FedAvg / FedAvgM >= 48 clients; two-moment optimizers >= 40
  * clients on vectors of >= 8 tiles per CU, >= 24 on vectors of >= 64) takes the persistent
  * kernel that parks results in LDS and writes them in bursts (stash: 0 never, < 0 always for
- * more than 8 clients, default 2).  Plain FedAvg from 16 clients on vectors of >= 72 tiles per
+ * more than 8 clients, default 2).  Plain FedAvg from 6 clients on vectors of >= 72 tiles per
  * CU takes the persistent kernel's wide-batch form (16 clients x 4 vectors in flight per lane,
- * phases of ten tiles); stash == -2 forces that form at every length, stash == -1 and 0 keep it
- * off.  Results do not depend on any of this.
+ * phases of ten tiles); stash == -2 forces that form at every length and client count, stash ==
+ * -1 and 0 keep it off.  Results do not depend on any of this.
  * Applies to launches made by the calling thread only (thread-local state).
  */
 int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);

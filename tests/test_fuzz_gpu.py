@@ -39,7 +39,7 @@ def test_random_reduce_rounds(seed):
         for it in range(10):
             n, K, opt, code, shift, hp, w = _case(rng)
             # 0: default routing, 1: persistent kernel, 2: tile kernel, 3: wide-batch persistent
-            # kernel where it applies (plain FedAvg, >= 16 clients), else the persistent kernel
+            # kernel where it applies (plain FedAvg), else the persistent kernel
             forced = int(rng.integers(0, 4))
             ops.tune(stash={0: 2, 1: -1, 2: 0, 3: -2}[forced])
             with_step = bool(rng.integers(0, 2))

@@ -386,7 +386,7 @@ def test_phased_persistent_kernel_beside_other_work_on_the_chip(opt, hp):
 
 
 @pytest.mark.parametrize("n", [7, 1027, 300007, 4500003, 12000004])
-@pytest.mark.parametrize("K", [16, 17, 49, 128])
+@pytest.mark.parametrize("K", [1, 2, 6, 16, 17, 49, 128])
 @pytest.mark.parametrize("nt", [1, 65, 1025], ids=["default", "one_group", "phases_of_4"])
 def test_wide_persistent_kernel_matches_oracle(n, K, nt):
     """The wide-batch persistent kernel (plain FedAvg on very long vectors) forced on at every
@@ -398,7 +398,8 @@ def test_wide_persistent_kernel_matches_oracle(n, K, nt):
     assert ops.reduce_kernel_name(32, 162_500_000, "none") == "reduce_park_kernel"
     assert ops.reduce_kernel_name(32, 162_500_000, "avgm") == "reduce_kernel"
     assert ops.reduce_kernel_name(32, 162_500_000, "adam") == "reduce_stash_kernel"
-    assert ops.reduce_kernel_name(15, 162_500_000, "none") == "reduce_kernel"
+    assert ops.reduce_kernel_name(6, 162_500_000, "none") == "reduce_park_kernel"
+    assert ops.reduce_kernel_name(5, 162_500_000, "none") == "reduce_kernel"
     assert ops.reduce_kernel_name(32, 65_000_000, "none") == "reduce_kernel"
     base, xs = make_clients(n, K)
     w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
