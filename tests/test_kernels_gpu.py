@@ -418,6 +418,21 @@ def test_wide_persistent_kernel_matches_oracle(n, K, nt):
         ops.tune()
 
 
+def test_wide_persistent_kernel_where_the_library_routes_to_it():
+    """A vector long enough for the default routing to pick the wide-batch persistent kernel
+    (several phases per group, a scalar tail after the 128-bit body): the oracle's bits."""
+    from appfl_amd import ops
+    n, K = 76_000_003, 6
+    assert ops.reduce_kernel_name(K, n, "none") == "reduce_park_kernel"
+    base, xs = make_clients(n, K, spike=False)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref = base.copy()
+    O.reduce_opt(xs, w, g_ref, None, None, O.OPT_NONE)
+    g = dev(base)
+    ops.reduce_opt([dev(x) for x in xs], w, g, None, None, "none")
+    assert_bits(g, g_ref, "g")
+
+
 def test_wide_persistent_kernel_after_client_chunks_and_beside_other_work():
     """K > FA_KCHUNK: the last chunk's launch starts from the carried step.  And with another
     stream's kernels holding CUs the phased launch still ends with the oracle's bits."""
