@@ -830,7 +830,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
 // tiles at a time in the same chip-wide, staggered phases.  Measured against the better of the
 // other two kernels (fraction of peak): 162.5 M elements x 32 clients 0.75 -> 0.85, x 16 0.765 ->
 // 0.80, x 64 0.80 -> 0.83; 120 M x 32 0.75 -> 0.815; 87 M x 16 / 32 / 64 0.77 / 0.75 / 0.79 -> 0.79
-// / 0.81 / 0.82; 325 M x 32 0.79 -> 0.82; level at 65 M elements and at 100 clients, behind below
+// / 0.81 / 0.82; 325 M x 32 0.79 -> 0.82; level at 65 M elements and at 128 clients, behind below
 // (47 M x 48: 0.76 against 0.79), and far behind under the optimizers, whose epilogue has
 // nothing to hide behind at one wave per SIMD (FedAdam 0.53-0.64 against 0.70-0.75; FedAvgM
 // -1...-3 %).  Short client lists gain as much (8 / 12 clients on 162.5 M: 0.72 / 0.75 -> 0.77 /
