@@ -835,8 +835,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
 // nothing to hide behind at one wave per SIMD (FedAdam 0.53-0.64 against 0.70-0.75; FedAvgM
 // -1...-3 %).  Short client lists gain as much (8 / 12 clients on 162.5 M: 0.72 / 0.75 -> 0.77 /
 // 0.80).  Phases of ten tiles (all that LDS holds) beat shorter ones here (4 / 6 / 8 / 10
-// tiles on 162.5 M x 32: 0.81 / 0.84 / 0.84 / 0.85).  Only the final form of a launch (weighted
-// step, apply; no step output).
+// tiles on 162.5 M x 32: 0.81 / 0.84 / 0.84 / 0.85).  It takes the final form of a launch
+// (weighted step and apply, no step output) and, as plain FedAvg whatever the optimizer, the
+// step-only forms (a client chunk that is not the last one; fa_reduce_step).
 template <int OPT>
 __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceArgs a) {
     constexpr int NV = 1 + (OPT != FA_OPT_NONE) + (OPT >= FA_OPT_ADAM);
@@ -876,7 +877,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
     const unsigned ntiles = (total - slot + gridDim.x - 1) / gridDim.x;
     const unsigned r0 = slot * tlen, r1 = a.n, tstride = gridDim.x * tlen;
     const unsigned nbytes = a.n * 16u;
-    float* dst[3] = {a.g, OPT != FA_OPT_NONE ? a.v : nullptr, OPT >= FA_OPT_ADAM ? a.m : nullptr};
+    // the step-only forms (a client chunk that is not the last, or no apply) leave the step
+    const bool whole = a.last && a.apply;
+    float* dst[3] = {whole ? a.g : a.step_out, OPT != FA_OPT_NONE ? a.v : nullptr, OPT >= FA_OPT_ADAM ? a.m : nullptr};
     for (unsigned ct = 0; ct < ntiles; ++ct) {
         unsigned idx[VPT];
 #pragma unroll
@@ -895,7 +898,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
                 t.x = v.e[0]; t.y = v.e[1]; t.z = v.e[2]; t.w = v.e[3];
                 return t;
             };
-            stash[j][0][p][threadIdx.x] = as_f4(r.g[p]);
+            stash[j][0][p][threadIdx.x] = as_f4(whole ? r.g[p] : r.s[p]);
             if (OPT != FA_OPT_NONE) stash[j][NV > 1 ? 1 : 0][p][threadIdx.x] = as_f4(r.v[p]);
             if (OPT >= FA_OPT_ADAM) stash[j][NV > 2 ? 2 : 0][p][threadIdx.x] = as_f4(r.m[p]);
         }
@@ -1417,8 +1420,12 @@ bool takes_stash_path(int opt, int K, uint64_t nvec) {
 template <int OPT, int VEC>
 int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
     if (VEC == 1) return launch_reduce_s<OPT, 1, 1, 8, true>(a, st);
-    if constexpr (OPT == FA_OPT_NONE) {
-        if (takes_park_path(OPT, a.K, a.n, a.last && a.apply && !a.step_out)) return launch_park<OPT>(a, st);
+    {
+        const bool step_only = (!a.last || !a.apply) && a.step_out;   // no optimizer in these forms
+        const bool final_form = a.last && a.apply && !a.step_out;
+        if ((step_only || (OPT == FA_OPT_NONE && final_form)) &&
+            takes_park_path(FA_OPT_NONE, a.K, a.n, true))
+            return launch_park<FA_OPT_NONE>(a, st);
     }
     if (takes_stash_path(OPT, a.K, a.n)) return launch_stash<OPT>(a, st);
     int vpt = g_shape.vpt, unroll = g_shape.unroll;

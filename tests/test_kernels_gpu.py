@@ -414,8 +414,36 @@ def test_wide_persistent_kernel_matches_oracle(n, K, nt):
             g.copy_(dev(base))
             ops.reduce_opt(dx, w, g, None, None, "none")
             assert_bits(g, g_ref, "g")
+        # the step-only form parks and writes the step instead
+        pre_ref = np.empty_like(base)
+        O.reduce_step(xs, w, base, pre_ref)
+        g.copy_(dev(base))
+        pre = torch.full((n,), 9.0, device="cuda")
+        ops.reduce_step(dx, w, g, pre)
+        assert_bits(pre, pre_ref, "step-only")
+        assert_bits(g, base, "g untouched")
     finally:
         ops.tune()
+
+
+def test_wide_persistent_kernel_carries_the_step_of_the_first_client_chunks():
+    """K > FA_KCHUNK under FedAdam with the wide-batch kernel forced on: the first chunk's
+    launch (plain FedAvg arithmetic, step only) parks and writes the partial step."""
+    from appfl_amd import ops
+    n, K = 300007, ops.kchunk() + 5
+    base, xs = make_clients(n, K, spike=False)
+    w = [1.0 / K] * K
+    g_ref, m_ref, v_ref = base.copy(), np.zeros_like(base), np.full_like(base, np.float32(1e-6))
+    O.reduce_opt(xs, w, g_ref, m_ref, v_ref, O.OPT_ADAM, **HP)
+    g, m, v = dev(base), dev(np.zeros_like(base)), dev(np.full_like(base, np.float32(1e-6)))
+    try:
+        ops.tune(stash=-2)
+        ops.reduce_opt([dev(x) for x in xs], w, g, m, v, "adam", step_ws=torch.empty_like(g), **HP)
+    finally:
+        ops.tune()
+    assert_bits(g, g_ref, "g")
+    assert_bits(m, m_ref, "m")
+    assert_bits(v, v_ref, "v")
 
 
 def test_wide_persistent_kernel_where_the_library_routes_to_it():
