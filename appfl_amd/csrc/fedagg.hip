@@ -1403,12 +1403,14 @@ int launch_reduce_u(const ReduceArgs& a, int unroll, hipStream_t st) {
 // one wave per SIMD at short client lists.  With the phases of odd and even XCDs half a phase
 // apart it is ahead from 40 clients on vectors of >= 8 tiles per CU (measured against the
 // tile-per-block kernel: +3 % at 25 M elements x 40-56 clients, +2.5 % / +6 % at 12 M x 48 / 100,
-// +5-6 % at 87 M x 32-48) and from 24 clients on vectors of >= 64 tiles per CU (+6 % at 87 M x
-// 24, +4-5 % at 162 M x 32); below that the tile-per-block kernel wins (25 M x 24-28: +5 %,
-// 12 M x 24-32: +2-8 %, 4.5 M x 32: +8 %).
+// +5-6 % at 87 M x 32-48), from 32 clients on vectors of >= 32 tiles per CU (+6-7 % at 35-60 M x
+// 32-36) and from 24 clients on vectors of >= 40 tiles per CU (+3-4 % at 47-60 M x 24-28, +6 % at
+// 87 M x 24, +4-5 % at 162 M x 32); below that the tile-per-block kernel wins or ties (25 M x
+// 24-28: +2-5 %, 25 M x 32-36 and 35 M x 24-28: within 1.5 %, 60 M x 20: +4 %, 12 M x 24-32: +2-8 %,
+// 4.5 M x 32: +8 %).
 bool stash_wins(int opt, int K, uint64_t tiles_per_cu) {
     if (opt <= FA_OPT_AVGM) return K >= 48 && tiles_per_cu >= 1;
-    return (K >= 40 && tiles_per_cu >= 8) || (K >= 24 && tiles_per_cu >= 64);
+    return (K >= 40 && tiles_per_cu >= 8) || (K >= 32 && tiles_per_cu >= 32) || (K >= 24 && tiles_per_cu >= 40);
 }
 bool takes_stash_path(int opt, int K, uint64_t nvec) {
     if (g_shape.stash < 0) return K > kStashUnroll;

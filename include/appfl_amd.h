@@ -76,7 +76,7 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * bits 8-12: tiles per phase, 0 = chosen per launch),
  * grid cap (<= 0: default) of the tile-per-block kernel, and from how many 16-KiB tiles per CU
  * a launch with a long client list (FedAvg / FedAvgM >= 48 clients; two-moment optimizers >= 40
- * clients on vectors of >= 8 tiles per CU, >= 24 on vectors of >= 64) takes the persistent
+ * clients on vectors of >= 8 tiles per CU, >= 32 on >= 32 tiles, >= 24 on >= 40 tiles) takes the persistent
  * kernel that parks results in LDS and writes them in bursts (stash: 0 never, < 0 always for
  * more than 8 clients, default 2).  Plain FedAvg from 6 clients on vectors of >= 72 tiles per
  * CU takes the persistent kernel's wide-batch form (16 clients x 4 vectors in flight per lane,
