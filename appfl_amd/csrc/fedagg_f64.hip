@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxBlocks = 1 << 16;
+constexpr int kMaxBlocks = 1 << 20;   // grid cap (covers a launch segment at one tile per block); larger inputs are walked grid-stride
 constexpr int kAhead = 8;   // client loads in flight per element
 
 struct Hyper64 {
