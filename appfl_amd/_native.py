@@ -26,6 +26,7 @@ _f = C.c_float
 _u64 = C.c_uint64
 
 FA_DT_F32, FA_DT_I64, FA_DT_I32 = range(3)
+FA_ROUTE_DEFAULT, FA_ROUTE_NO_PERSISTENT = 0, 1
 FA_ADMM_KCHUNK, FA_ADMM_BLOCKS = 64, 2048
 FA_ADMM_RES_WS = 2 + 2 * FA_ADMM_BLOCKS
 
@@ -43,6 +44,8 @@ SIGNATURES = {
     "fa_reduce_kernel_name": (C.c_char_p, [_i, _sz, _i]),
     "fa_tune": (_i, [_i, _i, _i, _i, _i]),
     "fa_reduce_opt": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),
+    "fa_reduce_opt_ex": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, C.c_uint, _p]),
+    "fa_debug_scribble_meeting_counters": (_i, [_p]),
     "fa_round": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p, _i, _i, _p, _p]),
     "fa_reduce_apply": (_i, [_p, _p, _i, _p, _sz, _p, _p]),
     "fa_reduce_opt_static": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p]),

@@ -98,6 +98,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._step_flat64: Optional[torch.Tensor] = None
         self._staged_for = None
         self._prestaged: Dict[Any, tuple] = {}   # client_id -> (row, model) staged on arrival
+        self._next_row = 0                       # slab rows handed out since the last round (never reused within one)
+        self._restaged = False                   # a client was staged twice: rows are no longer in arrival order
         self._row_of: list = []                  # slab row of the k-th client of this round
         self._chunks: Dict[tuple, "_ChunkState"] = {}    # streamed aggregation: working sets per key set
         # entries of the global state that streamed rounds created outside the flat layout
@@ -156,8 +158,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 if source is not None:
                     sizes = {k: v.numel() * v.element_size() for k, v in source.items()}
                 else:
+                    names_layout = self._names_layout()
                     sizes = {e.name: e.numel * torch.empty((), dtype=e.dtype).element_size()
-                             for e in self._names_layout().entries}
+                             for e in (names_layout.entries if names_layout is not None else [])}
                     sizes.update({k: v.numel() * v.element_size() for k, v in self._extra_state.items()})
                 if sum(sizes.values()) > self.model_chunk_size:
                     chunks = split_names_by_size(sizes, self.model_chunk_size)
@@ -255,19 +258,23 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         with self._lock:
             if self._layout is None:
                 self._init_global_state(local_model)
-            row = len(self._prestaged)
+            # a client staged again takes a NEW row (its old one may still be read by a fold
+            # enqueued earlier); rows are counted, not derived from the dict, which stops growing then
+            row = self._next_row
+            self._next_row = row + 1
             hint = cfg_get(self.aggregator_configs, "num_clients", 0) or 0
             self._slab.reserve(max(row + 1, int(hint)), preserve=row)
             if row == 0:
                 self._slab.begin_round()
             # the windows' events are kept: `aggregate` can then start on the head of this row
             # while its tail still travels, and send results back meanwhile (`_round_pipelined`)
-            self._slab.upload(row, local_model, fill_missing_from=self._flats, window=self.STAGE_WINDOW)
+            self._slab.upload(row, local_model, fill_missing_from=self._fill_source(), window=self.STAGE_WINDOW)
             if self._slab.has_device_sources:
                 # the caller may overwrite its device tensors as soon as this returns
                 self._slab.wait_uploads()
             if client_id in self._prestaged:
-                self._folded = {"w": None}          # a client staged twice: rows no longer in arrival order
+                self._restaged = True
+                self._folded = {"w": None}
             self._prestaged[client_id] = (row, local_model)
             self._fold_on_arrival(row, int(hint))
 
@@ -292,8 +299,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         clients in the same order as the fused kernel, cut between two clients: same bits."""
         lay = self._layout
         n_step = lay.count[STEP]
-        if not (self.FOLD_ON_ARRIVAL and self._fold_means and self.device.type == "cuda"
-                and num_clients >= 2 and row >= 1 and n_step >= self.PIPELINE_MIN_ELEMENTS
+        if not (self.FOLD_ON_ARRIVAL and not self._restaged and self._fold_means
+                and self.device.type == "cuda" and num_clients >= 2 and row >= 1 and n_step >= self.PIPELINE_MIN_ELEMENTS
                 and not lay.n_f64 and hasattr(self._ops, "round_sync")
                 and getattr(type(self).compute_steps, "_appfl_amd_native", False)):
             return
@@ -350,7 +357,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         if self._staged_for is not None and self._staged_for is local_models:
             return
         K = len(local_models)
-        taken = len(self._prestaged)
+        taken = self._next_row
         reuse = {cid: row for cid, (row, model) in self._prestaged.items()
                  if cid in local_models and local_models[cid] is model}
         fresh = K - len(reuse)
@@ -363,13 +370,14 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             if cid in reuse:
                 self._row_of.append(reuse[cid])
                 continue
-            self._slab.upload(nxt, model, fill_missing_from=self._flats)
+            self._slab.upload(nxt, model, fill_missing_from=self._fill_source())
             self._row_of.append(nxt)
             nxt += 1
         self._uploads_pending = defer_wait
         if not defer_wait:
             self._slab.end_round()
         self._prestaged = {}
+        self._next_row, self._restaged = 0, False
         self._folded_round, self._folded = self._folded, None
 
     def _hyper(self) -> Dict[str, float]:
@@ -378,9 +386,16 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
     def _ensure_moments(self) -> None:
         """Subclasses allocate m / v on the first round (e.g. fedadam_aggregator.py:41-50)."""
 
+    def _row_indices(self, K: int):
+        """Slab rows of this round's K clients, in client order."""
+        return self._row_of if len(self._row_of) == K else range(K)
+
     def _rows(self, K: int, byte_offset: int):
-        rows = self._row_of if len(self._row_of) == K else range(K)
-        return [self._slab.row_ptr(r) + byte_offset for r in rows]
+        return [self._slab.row_ptr(r) + byte_offset for r in self._row_indices(K)]
+
+    def _fill_source(self):
+        """Where a client's missing weighted entries are filled from (the global flat vectors)."""
+        return self._flats
 
     # -- compute_steps: fedavg_aggregator.py:322-368 ------------------------------------------------
     @_native
@@ -650,25 +665,36 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     weights.append(1.0 / K)
             self._slab.reserve(K)
             self._slab.begin_round()
-            with torch.cuda.stream(self._slab.copy_stream):
+            with self._slab._on_copy_stream():
                 for k, p in enumerate(payloads):
                     flat = p["flat"].detach().reshape(-1)
                     if flat.numel() != n:
                         raise ValueError(f"flat payload has {flat.numel()} elements, expected {n}")
                     self._slab.row_view(k, 0, n, torch.float32).copy_(
                         flat.to(torch.float32), non_blocking=False)
-                ev = torch.cuda.Event()
-                ev.record(self._slab.copy_stream)
+                ev = self._slab._copy_event()
             self._slab.last_copy = ev
             self._slab.end_round()
+            self._row_of = []
             ws = None
-            if K > ops.kchunk():
+            if K > self._ops.kchunk():
                 ws = torch.empty(n, dtype=torch.float32, device=self.device)
-            ops.weighted_mix(self._rows(K, 0), weights, self._flats["f32"],
-                             "sum_set" if first_round else "sum_add", acc_ws=ws, n=n)
-            out = self._download()
+            self._ops.weighted_mix(self._rows(K, 0), weights, self._flats["f32"],
+                                   "sum_set" if first_round else "sum_add", acc_ws=ws, n=n)
+            out = FedAvgAggregator._download(self)
             self._sync_model(self.model, out)
             return out
+
+    def _state_value(self, key) -> Optional[torch.Tensor]:
+        """The device tensor that holds the global value of entry `key` (writable), or None."""
+        main = self._layout
+        if main is not None and key in main.by_name:
+            return main.view(self._flats, key)
+        return self._extra_state.get(key)
+
+    def _state_written(self, key) -> None:
+        """Called after the tensor `_state_value(key)` returned was overwritten (subclasses that
+        keep further copies of the state refresh them)."""
 
     # -- streamed aggregation: fedavg_aggregator.py:406-497 ------------------------------------------
     def _aggregate_chunk(self, local_models, **kwargs) -> Dict:
@@ -680,12 +706,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         chunk_keys = list(list(kwargs["_chunk_keys"].values())[0])
         with self._lock:
             first = next(iter(local_models.values()))
-            main = self._layout
-
-            def current(key):
-                if main is not None and key in main.by_name:
-                    return main.view(self._flats, key)
-                return self._extra_state.get(key)
+            current = self._state_value
 
             init = {}
             for k in chunk_keys:
@@ -710,28 +731,30 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 st.slab.upload(k, model, fill_missing_from=st.flats)
             st.slab.end_round()
             rows = lambda off: [st.slab.row_ptr(k) + off for k in range(K)]
+            ops_ = self._ops
             if lay.count[STEP]:
                 ws = None
-                if K > ops.kchunk():
+                if K > ops_.kchunk():
                     ws = torch.empty(lay.count[STEP], dtype=torch.float32, device=self.device)
-                ops.reduce_opt(rows(0), self._client_weights(local_models), st.flats["f32"],
-                               step_ws=ws, n=lay.count[STEP])
+                ops_.reduce_opt(rows(0), self._client_weights(local_models), st.flats["f32"],
+                                step_ws=ws, n=lay.count[STEP])
             if lay.count[STEP_F64]:
                 ws = None
-                if K > ops.kchunk():
+                if K > ops_.kchunk():
                     ws = torch.empty(lay.count[STEP_F64], dtype=torch.float64, device=self.device)
-                ops.reduce_opt(rows(lay.seg_byte[STEP_F64]), self._client_weights(local_models),
-                               st.flats["f64"], step_ws=ws, n=lay.count[STEP_F64])
+                ops_.reduce_opt(rows(lay.seg_byte[STEP_F64]), self._client_weights(local_models),
+                                st.flats["f64"], step_ws=ws, n=lay.count[STEP_F64])
             if lay.count[MEAN_I64]:
-                ops.mean(rows(lay.seg_byte[MEAN_I64]), st.flats["i64"], n=lay.count[MEAN_I64])
+                ops_.mean(rows(lay.seg_byte[MEAN_I64]), st.flats["i64"], n=lay.count[MEAN_I64])
             if lay.count[MEAN_I32]:
-                ops.mean(rows(lay.seg_byte[MEAN_I32]), st.flats["i32"], n=lay.count[MEAN_I32])
+                ops_.mean(rows(lay.seg_byte[MEAN_I32]), st.flats["i32"], n=lay.count[MEAN_I32])
             # the chunk's new values become part of the global state
             with torch.no_grad():
                 for n in init:
                     cur = current(n)
                     if cur is not None:
                         cur.copy_(lay.view(st.flats, n))
+                        self._state_written(n)
                     else:
                         self._extra_state[n] = lay.view(st.flats, n).clone()
             out = _download_flats(lay, st.flats, self._dl)

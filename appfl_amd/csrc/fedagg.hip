@@ -75,7 +75,8 @@ struct ReduceArgs {
                 // result bursts, bit 0 = and again after the bursts have drained; 0 = no phases;
                 // bits 2-3 = groups of XCDs with staggered phases (0: one group)
     int phase_tiles;       // persistent kernel: tiles per phase (one burst); 0 = all the chip can park
-    unsigned* sync_word;   // counter the blocks of this launch meet on (sync != 0); zero between launches
+    unsigned* sync_word;   // counter the blocks of this launch meet on (sync != 0)
+    unsigned sync_epoch;   // this launch's tag in the counter's high bits: the first block to find another tag restarts the count
     Hyper h;
     MeanTail mt;
 };
@@ -477,12 +478,15 @@ __device__ __forceinline__ void burst_store(float* base, unsigned bytes, unsigne
 // depend on it.
 constexpr unsigned kSyncPolls = 96;
 
-// Layout of a meeting counter: arrivals in the low bits, blocks that have left the kernel above
-// them.  The last block to leave puts the word back to zero, so a counter needs no clearing
-// between launches (a memset per launch costs more than a round of a small model's kernel).
-constexpr unsigned kLeaveShift = 20;
-constexpr unsigned kLeaveOne = 1u << kLeaveShift;
-constexpr unsigned kArriveMask = kLeaveOne - 1u;
+// Layout of a meeting counter: arrivals in the low kEpochShift bits, above them the tag (epoch)
+// of the launch that counts in it.  Nothing is cleared between launches, neither by the host (a
+// memset per launch costs more than a round of a small model's kernel) nor by the last block to
+// leave: every block starts by looking at the tag, and the first one that finds another launch's
+// tag -- or what an aborted or overlapping launch left behind -- restarts the word at (own tag,
+// zero arrivals).  A counter therefore heals with the next launch that uses it, whatever it holds.
+constexpr unsigned kEpochShift = 20;
+constexpr unsigned kArriveMask = (1u << kEpochShift) - 1u;
+constexpr unsigned kEpochs = (1u << (32 - kEpochShift)) - 1u;   // tags 1..kEpochs; 0 = never used
 
 struct GridMeet {
     unsigned* word;
@@ -490,6 +494,20 @@ struct GridMeet {
     bool gave_up;
     unsigned blocks;     // blocks that meet on this word
 };
+
+// First access of every block of a phased launch to its counter.
+__device__ __forceinline__ void grid_meet_enter(GridMeet& m, unsigned epoch) {
+    if (threadIdx.x == 0) {
+        unsigned cur = __hip_atomic_load(m.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // bounded: the swap only fails when another block changed the word meanwhile -- one of this
+        // launch (then the tag matches) or of a launch sharing the slot (timing only; try a few times)
+        for (int tries = 0; tries < 8 && (cur >> kEpochShift) != epoch; ++tries) {
+            if (__hip_atomic_compare_exchange_strong(m.word, &cur, epoch << kEpochShift, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                break;
+        }
+    }
+}
 
 __device__ __forceinline__ void grid_meet(GridMeet& m) {
     ++m.arrivals;
@@ -515,18 +533,11 @@ __device__ __forceinline__ void grid_meet(GridMeet& m) {
     __syncthreads();
 }
 
-// Every block of a phased launch calls this exactly once, as its last access to the counter.  A
-// block that leaves before the others still counts for the meetings it skips; the block that
-// finds all the others gone (their accesses to the word all precede their leave in the word's
-// modification order) zeroes it for the launch that gets this slot next.
+// Every block of a phased launch calls this exactly once, as its last access to the counter: a
+// block that leaves before the others still counts for the meetings it skips.
 __device__ __forceinline__ void grid_meet_leave(GridMeet& m, unsigned expected) {
-    if (threadIdx.x == 0) {
-        const unsigned skipped = expected > m.arrivals ? expected - m.arrivals : 0u;
-        const unsigned old = __hip_atomic_fetch_add(m.word, kLeaveOne + skipped, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-        if ((old >> kLeaveShift) == m.blocks - 1u)
-            __hip_atomic_store(m.word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0 && expected > m.arrivals)
+        __hip_atomic_fetch_add(m.word, expected - m.arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The client loop of the persistent kernel is software-pipelined ACROSS tiles: two register
@@ -612,6 +623,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
             shift = group * P / groups;
         }
         if (phased) meetings = ((most + shift + P - 1) / P) * (((a.sync & 1) ? 1u : 0u) + ((a.sync & 2) ? 1u : 0u));
+        if (phased) grid_meet_enter(meet, a.sync_epoch);
         if (slot >= total) {
             if (phased) grid_meet_leave(meet, meetings);
             return;
@@ -870,6 +882,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
         shift = group * P / groups;
     }
     if (phased) meetings = (most + shift + P - 1) / P;
+    if (phased) grid_meet_enter(meet, a.sync_epoch);
     if (slot >= total) {
         if (phased) grid_meet_leave(meet, meetings);
         return;
@@ -1271,6 +1284,8 @@ struct Shape {
                      // several tiles of its own
 };
 thread_local Shape g_shape = {0, 8, 1, kMaxBlocks, 2};
+// FA_ROUTE_* flags of the call being dispatched on this thread (fa_reduce_opt_ex); 0 otherwise.
+thread_local unsigned g_call_flags = 0;
 constexpr unsigned kLeanTileVectors = 1u << 20;   // 16 MiB of g
 thread_local int g_write_through = 1;   // fa_tune's nt field: bit 1 set = plain result stores
 thread_local int g_interleave = 1;      // fa_tune's nt field: bit 2 set = contiguous per-block ranges in the persistent kernel
@@ -1300,11 +1315,14 @@ int device_cu_count() {
 }  // namespace
 
 // Meeting counters of the persistent kernel's launches: kSyncSlots slots of one 256-byte line
-// each, handed out round-robin.  They start at zero (static storage) and every launch leaves
-// its counter at zero again (grid_meet_leave), so nothing is cleared between launches; a slot
-// comes round again after kSyncSlots launches, which are assumed not to be all in flight at
-// once.  (The name is a host-side handle; the per-device address comes from
-// hipGetSymbolAddress.)
+// each.  A slot belongs to a STREAM: launches on one stream run one after the other, so a slot
+// never serves two launches at once as long as a device has at most kSyncSlots streams launching
+// phased rounds (beyond that the oldest assignment is taken over and two streams may share a
+// slot for a while: their meetings then end early or time out, results are unaffected).  Nothing
+// is cleared between launches: every launch carries a tag, and the first of its blocks that
+// finds another tag in the word restarts it (grid_meet_enter), so whatever an overlapping or
+// aborted launch left behind is gone with the next launch.  (The name is a host-side handle; the
+// per-device address comes from hipGetSymbolAddress.)
 static __device__ __align__(256) unsigned sync_words[64 * 64];
 
 namespace {
@@ -1313,13 +1331,16 @@ constexpr int kSyncSlots = 64;
 constexpr int kMaxDevices = 64;
 std::mutex g_symbol_mutex;
 unsigned* g_sync_ptr[kMaxDevices] = {nullptr};
-unsigned g_sync_next[kMaxDevices] = {0};
+struct SyncSlots {
+    hipStream_t stream[kSyncSlots];
+    unsigned epoch[kSyncSlots];
+    int used;       // assigned slots
+    int victim;     // next assignment to take over once all are in use
+};
+SyncSlots g_sync_slots[kMaxDevices];
 
-// A meeting counter for one launch on the current device (NULL: run without meetings).
-unsigned* next_sync_word() {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    std::lock_guard<std::mutex> hold(g_symbol_mutex);
+// Address of the current device's counters (NULL: unavailable, run without meetings).
+unsigned* sync_words_of(int dev) {
     if (!g_sync_ptr[dev]) {
         unsigned* p = nullptr;
         if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(sync_words)) != hipSuccess || !p) {
@@ -1328,13 +1349,34 @@ unsigned* next_sync_word() {
         }
         g_sync_ptr[dev] = p;
     }
-    return g_sync_ptr[dev] + 64 * (g_sync_next[dev]++ % kSyncSlots);
+    return g_sync_ptr[dev];
+}
+
+// The meeting counter of stream `st` on the current device and the tag of this launch in it.
+unsigned* next_sync_word(hipStream_t st, unsigned* epoch) {
+    int dev = -1;
+    *epoch = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> hold(g_symbol_mutex);
+    unsigned* base = sync_words_of(dev);
+    if (!base) return nullptr;
+    SyncSlots& t = g_sync_slots[dev];
+    int slot = -1;
+    for (int i = 0; i < t.used; ++i)
+        if (t.stream[i] == st) { slot = i; break; }
+    if (slot < 0) {
+        slot = t.used < kSyncSlots ? t.used++ : (t.victim++ % kSyncSlots);
+        t.stream[slot] = st;
+    }
+    t.epoch[slot] = t.epoch[slot] % (kEpochs - 1u) + 1u;   // 1..kEpochs-1 (the all-ones tag is never handed out)
+    *epoch = t.epoch[slot];
+    return base + 64 * slot;
 }
 
 template <int OPT, int MODE>
 int launch_stash_m(const ReduceArgs& a0, hipStream_t st) {
     ReduceArgs a = a0;
-    a.sync_word = (a.sync && a.il) ? next_sync_word() : nullptr;
+    a.sync_word = (a.sync && a.il) ? next_sync_word(st, &a.sync_epoch) : nullptr;
     hipLaunchKernelGGL((reduce_stash_kernel<OPT, MODE>), dim3(device_cu_count()), dim3(kThreads), 0, st, a);
     return launch_status();
 }
@@ -1342,7 +1384,7 @@ int launch_stash_m(const ReduceArgs& a0, hipStream_t st) {
 template <int OPT>
 int launch_park(const ReduceArgs& a0, hipStream_t st) {
     ReduceArgs a = a0;
-    a.sync_word = a.sync ? next_sync_word() : nullptr;
+    a.sync_word = a.sync ? next_sync_word(st, &a.sync_epoch) : nullptr;
     hipLaunchKernelGGL((reduce_park_kernel<OPT>), dim3(device_cu_count()), dim3(kThreads), 0, st, a);
     return launch_status();
 }
@@ -1357,6 +1399,7 @@ constexpr uint64_t kParkMinTilesPerCu = 72;
 constexpr int kParkMinClients = 6;
 bool takes_park_path(int opt, int K, uint64_t nvec, bool final_form) {
     if (opt != FA_OPT_NONE || !final_form || K > FA_KCHUNK) return false;
+    if (g_call_flags & FA_ROUTE_NO_PERSISTENT) return false;
     if (g_shape.stash == -2) return true;
     if (g_shape.stash <= 0 || K < kParkMinClients) return false;
     const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
@@ -1413,6 +1456,7 @@ bool stash_wins(int opt, int K, uint64_t tiles_per_cu) {
     return (K >= 40 && tiles_per_cu >= 8) || (K >= 32 && tiles_per_cu >= 32) || (K >= 24 && tiles_per_cu >= 40);
 }
 bool takes_stash_path(int opt, int K, uint64_t nvec) {
+    if (g_call_flags & FA_ROUTE_NO_PERSISTENT) return false;
     if (g_shape.stash < 0) return K > kStashUnroll;
     const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
     return g_shape.stash > 0 && nvec >= per_cu * static_cast<uint64_t>(g_shape.stash) &&
@@ -1909,6 +1953,33 @@ int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float
     ReduceCall c{x, w, K, g, nullptr, m, v, n, opt, make_hyper(lr, beta1, beta2, tau),
                  step_out, step_ws, 1};
     return reduce_dispatch(c, as_stream(stream));
+}
+
+int fa_reduce_opt_ex(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+                     size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                     float* step_out, float* step_ws, unsigned flags, fa_stream_t stream) {
+    if (flags & ~static_cast<unsigned>(FA_ROUTE_NO_PERSISTENT)) return FA_ERR_INVALID;
+    ReduceCall c{x, w, K, g, nullptr, m, v, n, opt, make_hyper(lr, beta1, beta2, tau),
+                 step_out, step_ws, 1};
+    g_call_flags = flags;
+    const int rc = reduce_dispatch(c, as_stream(stream));
+    g_call_flags = 0;
+    return rc;
+}
+
+int fa_debug_scribble_meeting_counters(fa_stream_t stream) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_code(e);
+    if (dev < 0 || dev >= kMaxDevices) return FA_ERR_INVALID;
+    unsigned* base = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(g_symbol_mutex);
+        base = sync_words_of(dev);
+    }
+    if (!base) return FA_ERR_INVALID;
+    e = hipMemsetAsync(base, 0xFF, sizeof(unsigned) * 64 * kSyncSlots, as_stream(stream));
+    return e == hipSuccess ? FA_OK : hip_code(e);
 }
 
 static int round_body(const float* const* x, const double* w, int K, float* g, float* m, float* v,

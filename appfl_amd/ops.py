@@ -69,15 +69,30 @@ def reduce_kernel_name(K: int, n: int, opt: str = "none") -> str:
 
 
 def tune(vpt: int = 0, unroll: int = 8, nt: int = 1, max_blocks: int = 0, stash: int = 2) -> None:
+    """Benchmark knob (fa_tune): launch shape of the reduce kernels for the launches the CALLING
+    THREAD makes from now on; launches of other threads (a scheduler's) are not affected.  Called
+    without arguments it restores every default.  Product code never calls it: a caller that
+    needs one round kept off the persistent kernels passes ``persistent=False`` to `reduce_opt`."""
     N.check(N.load().fa_tune(vpt, unroll, nt, max_blocks, stash), "fa_tune")
+
+
+def scribble_meeting_counters(device=None) -> None:
+    """Test hook (fa_debug_scribble_meeting_counters) on the current stream of `device`."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        N.check(N.load().fa_debug_scribble_meeting_counters(st), "fa_debug_scribble_meeting_counters")
 
 
 def reduce_opt(x: Sequence[torch.Tensor], w: Sequence[float], g: torch.Tensor,
                m: Optional[torch.Tensor] = None, v: Optional[torch.Tensor] = None,
                opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
                tau: float = 0.0, step_out: Optional[torch.Tensor] = None,
-               step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
-    """Fused weighted step + server optimizer + apply over ``g[:n]`` (fa_reduce_opt)."""
+               step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None,
+               persistent: bool = True) -> None:
+    """Fused weighted step + server optimizer + apply over ``g[:n]`` (fa_reduce_opt).
+    ``persistent=False`` (fp32 only; fa_reduce_opt_ex with FA_ROUTE_NO_PERSISTENT) keeps this call
+    off the one-block-per-CU kernels, for rounds that run beside other kernels on the GPU."""
     n = g.numel() if n is None else n
     if len(x) != len(w):
         raise ValueError("one weight per client buffer")
@@ -85,10 +100,14 @@ def reduce_opt(x: Sequence[torch.Tensor], w: Sequence[float], g: torch.Tensor,
         if t is not None and t.numel() < n:
             raise ValueError("state / workspace tensor shorter than n")
     fn, dt = _float_entry("fa_reduce_opt", g)
-    rc = fn(_check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x),
+    head = (_check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x),
             _dev(g, dt), _dev(m, dt), _dev(v, dt), n,
             OPT_CODES[opt], float(lr), float(beta1), float(beta2), float(tau),
-            _dev(step_out, dt), _dev(step_ws, dt), _stream(g))
+            _dev(step_out, dt), _dev(step_ws, dt))
+    if not persistent and dt == torch.float32:
+        rc = N.load().fa_reduce_opt_ex(*head, N.FA_ROUTE_NO_PERSISTENT, _stream(g))
+    else:
+        rc = fn(*head, _stream(g))
     N.check(rc, "fa_reduce_opt")
 
 

@@ -123,37 +123,95 @@ def gather_rows(smap: ShardMap, g: torch.Tensor, out: torch.Tensor, group=None,
     return works
 
 
+# Whether the rounds of a pipelined sharded round (kernel on block row p+1 beside the all-gather
+# of row p) may take the one-block-per-CU persistent kernels.  Measured on one MI355X with a
+# device-to-device copy kernel standing in for RCCL's gather on a second stream
+# (tools/coresidency_probe.py; the log sits with the profiles): see the note at its definition's
+# use below.  A per-call routing flag of the C ABI (FA_ROUTE_NO_PERSISTENT), not process state.
+PERSISTENT_BESIDE_GATHER = False
+
+
 def round_gather_pipelined(ops, smap: ShardMap, x: Sequence, w: Sequence[float], g, m, v, opt: str,
-                           hp: dict, out: torch.Tensor, group=None, step_ws=None) -> torch.Tensor:
+                           hp: dict, out: torch.Tensor, group=None, step_ws=None,
+                           persistent: Optional[bool] = None) -> torch.Tensor:
     """The sliced round followed by the all-gather of the new model, pipelined over the block
     rows: the fused kernel runs on block p, then its row's all-gather is enqueued (RCCL works
     on its own stream) while the kernel of block p+1 runs.  Every rank enqueues every gather,
     also for rows in which its own block is empty.  On xGMI the gather of a large model takes
-    about as long as the local round, so the pipeline hides whichever is shorter."""
+    about as long as the local round, so the pipeline hides whichever is shorter.
+    `persistent`: whether the kernels may be the one-block-per-CU ones (default: yes when nothing
+    runs beside them -- one rank or one block row --, else PERSISTENT_BESIDE_GATHER)."""
     if out.numel() < smap.P:
         raise ValueError("gather buffer shorter than the padded vector")
-    # While a gather is in flight its copy kernels hold some CUs.  The persistent reduce kernel
-    # wants EVERY CU for one block each (all of a CU's LDS and registers), so beside a running
-    # gather its last blocks would wait for the gather to end and the pipeline would serialise;
-    # the tile-per-block kernel (many small blocks, 1 % slower on its own) shares the chip.
-    shared = smap.world > 1 and smap.pieces > 1 and hasattr(ops, "tune")
-    if shared:
-        ops.tune(stash=0)
+    if persistent is None:
+        persistent = PERSISTENT_BESIDE_GATHER or smap.world == 1 or smap.pieces == 1
+    extra = {} if persistent else {"persistent": False}
     works = []
-    try:
-        for p in range(smap.pieces):
-            a, live = p * smap.per, smap.live(p)
-            if live > 0:
-                ops.reduce_opt([_shift(c, a) for c in x], list(w), g[a:],
-                               None if m is None else m[a:], None if v is None else v[a:], opt,
-                               step_ws=None if step_ws is None else step_ws[a:], n=live, **hp)
-            works += gather_rows(smap, g, out, group, rows=[p], async_op=True)
-    finally:
-        if shared:
-            ops.tune()
+    for p in range(smap.pieces):
+        a, live = p * smap.per, smap.live(p)
+        if live > 0:
+            ops.reduce_opt([_shift(c, a) for c in x], list(w), g[a:],
+                           None if m is None else m[a:], None if v is None else v[a:], opt,
+                           step_ws=None if step_ws is None else step_ws[a:], n=live, **hp, **extra)
+        works += gather_rows(smap, g, out, group, rows=[p], async_op=True)
     for wk in works:
         wk.wait()
     return out
+
+
+def reduce_scatter_row(smap: ShardMap, partial: torch.Tensor, step: torch.Tensor, p: int, group=None):
+    """Sum over ranks of block row p of the full-length partial step `partial` (P elements); this
+    rank keeps its block in `step` (L elements).  Returns the pending work or None."""
+    a, b = smap.row(p)
+    dst = step[p * smap.per:(p + 1) * smap.per]
+    if smap.world == 1:
+        dst.copy_(partial[a:b])
+        return None
+    if dist.get_backend(group) == "gloo":
+        # gloo has no reduce-scatter; CPU rehearsals all-reduce the row and keep their block
+        dist.all_reduce(partial[a:b], group=group)
+        dst.copy_(partial[a + smap.rank * smap.per:a + (smap.rank + 1) * smap.per])
+        return None
+    return dist.reduce_scatter_tensor(dst, partial[a:b], op=dist.ReduceOp.SUM, group=group,
+                                      async_op=True)
+
+
+def round_whole_update(ops, smap: ShardMap, my_clients: Sequence, my_weights: Sequence[float],
+                       g, m, v, opt: str, hp: dict, g_full: torch.Tensor, partial: torch.Tensor,
+                       step: torch.Tensor, group=None, apply: bool = True,
+                       step_full: Optional[torch.Tensor] = None) -> None:
+    """One round where this rank holds WHOLE updates of some clients (`my_clients[k]`: n elements,
+    device tensors or raw device addresses; `my_weights`: their weights in the whole round; a
+    rank may hold none).  Per block row: partial weighted step of the own clients against the
+    replicated `g_full`, RCCL reduce-scatter (sum over ranks); then the optimizer epilogue and the
+    apply on the own block (`g`, `m`, `v`: L elements) and the all-gather of the row into `g_full`
+    -- both collectives pipelined behind the kernels of the next row.  `apply=False` stops after
+    the epilogue and gathers the STEP into `step_full` instead (compute_steps)."""
+    n = smap.n
+    scatters = []
+    if not len(my_clients):
+        partial.zero_()
+    for p in range(smap.pieces):
+        a, b = smap.row(p)
+        b = min(b, n)
+        if len(my_clients) and b > a:
+            ops.reduce_step([_shift(c, a) for c in my_clients], list(my_weights), g_full[a:],
+                            partial[a:], n=b - a)
+        scatters.append(reduce_scatter_row(smap, partial, step, p, group))
+    gathers = []
+    for p in range(smap.pieces):
+        if scatters[p] is not None:
+            scatters[p].wait()
+        a, live = p * smap.per, smap.live(p)
+        if live:
+            if opt != "none":
+                ops.server_opt_step(step[a:], None if m is None else m[a:], v[a:], opt, n=live, **hp)
+            if apply:
+                ops.apply_step(g[a:], step[a:], n=live)
+        gathers += gather_rows(smap, g if apply else step, g_full if apply else step_full, group,
+                               rows=[p], async_op=True)
+    for wk in gathers:
+        wk.wait()
 
 
 class ShardedFlatAggregator:
@@ -227,53 +285,15 @@ class ShardedFlatAggregator:
                                       self.v, self.opt, self.hp, out, self.group, step_ws)
 
     # -- whole-update mode ------------------------------------------------------------------
-    def _reduce_scatter_row(self, p: int):
-        """Sum over ranks of block row p of the partial step; this rank keeps its block."""
-        a, b = self.map.row(p)
-        dst = self._step[p * self.map.per:(p + 1) * self.map.per]
-        if self.world == 1:
-            dst.copy_(self._partial[a:b])
-            return None
-        if dist.get_backend(self.group) == "gloo":
-            # gloo has no reduce-scatter; CPU rehearsals all-reduce the row and keep their block
-            dist.all_reduce(self._partial[a:b], group=self.group)
-            dst.copy_(self._partial[a + self.rank * self.map.per:a + (self.rank + 1) * self.map.per])
-            return None
-        return dist.reduce_scatter_tensor(dst, self._partial[a:b], op=dist.ReduceOp.SUM,
-                                          group=self.group, async_op=True)
-
     def round_whole(self, my_clients: Sequence[torch.Tensor], my_weights: Sequence[float]) -> None:
         """One round where this rank holds whole updates of SOME clients (`my_clients[k]` has n
-        elements; `my_weights` are their global weights; a rank may hold none).  Per block row:
-        partial step against the replicated g, reduce-scatter; then optimizer + apply on the
-        own block and the all-gather of the row -- both collectives pipelined behind the
-        kernels of the next row."""
+        elements; `my_weights` are their global weights; a rank may hold none): see
+        `round_whole_update`."""
         smap = self.map
         if self.g_full is None:
             self.g_full = self.all_gather_global()
         if self._partial is None:
             self._partial = torch.zeros(smap.P, dtype=torch.float32, device=self.device)
             self._step = torch.zeros(self.L, dtype=torch.float32, device=self.device)
-        scatters = []
-        if not len(my_clients):
-            self._partial.zero_()
-        for p in range(smap.pieces):
-            a, b = smap.row(p)
-            b = min(b, self.n)
-            if len(my_clients) and b > a:
-                self.ops.reduce_step([_shift(c, a) for c in my_clients], list(my_weights),
-                                     self.g_full[a:], self._partial[a:], n=b - a)
-            scatters.append(self._reduce_scatter_row(p))
-        gathers = []
-        for p in range(smap.pieces):
-            if scatters[p] is not None:
-                scatters[p].wait()
-            a, live = p * smap.per, smap.live(p)
-            if live:
-                if self.opt != "none":
-                    self.ops.server_opt_step(self._step[a:], None if self.m is None else self.m[a:],
-                                             self.v[a:], self.opt, n=live, **self.hp)
-                self.ops.apply_step(self.g[a:], self._step[a:], n=live)
-            gathers += gather_rows(smap, self.g, self.g_full, self.group, rows=[p], async_op=True)
-        for wk in gathers:
-            wk.wait()
+        round_whole_update(self.ops, smap, my_clients, my_weights, self.g, self.m, self.v, self.opt,
+                           self.hp, self.g_full, self._partial, self._step, self.group)

@@ -7,9 +7,12 @@
  * enqueues work on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
  * returns.  Calls on one stream execute in order.  The library is thread-compatible
  * (concurrent calls must use different buffers); the only device state it owns are two
- * static arrays per GPU: 16 KiB of meeting counters its persistent reduce kernel uses for
- * timing only (a slot per launch, which the launch itself leaves at zero again; results never
- * depend on them) and the workspace of fa_reduce_opt_static.
+ * static arrays per GPU, resident from the moment the library's code object is loaded on that
+ * GPU: 16 KiB of meeting counters its persistent reduce kernel uses for timing only (a slot per
+ * stream; every launch tags the slot and restarts a counter it finds with another tag, so
+ * nothing is cleared between launches and a counter that an aborted or overlapping launch left
+ * inconsistent is good again with the next launch; results never depend on them) and the
+ * workspace of fa_reduce_opt_static.
  *
  * Arithmetic contract: each documented formula is evaluated as separately rounded IEEE fp32
  * operations in the written order (no FMA contraction, correctly rounded / and sqrt, denormals
@@ -111,6 +114,28 @@ int fa_reduce_opt(const float* const* x, const double* w, int K, float* g, float
                   float* step_out, float* step_ws, fa_stream_t stream);
 
 /*
+ * fa_reduce_opt with a per-call routing word (no counterpart in the reference).  flags = 0 is
+ * fa_reduce_opt.  FA_ROUTE_NO_PERSISTENT keeps this call off the two persistent kernels (one
+ * block per CU, all of a CU's LDS and registers each) whatever the length and client count, so
+ * that it runs as the tile-per-block kernel of many small blocks: for callers that run the
+ * round BESIDE other kernels on the same GPU -- the sharded aggregator's rounds next to RCCL's
+ * all-gather of the previous block row -- where a one-block-per-CU grid would wait for the other
+ * kernel's blocks to leave.  Same results bit for bit; unknown flag bits return FA_ERR_INVALID.
+ */
+enum { FA_ROUTE_DEFAULT = 0, FA_ROUTE_NO_PERSISTENT = 1 };
+int fa_reduce_opt_ex(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+                     size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                     float* step_out, float* step_ws, unsigned flags, fa_stream_t stream);
+
+/*
+ * Test hook (no counterpart in the reference): overwrites every meeting counter of the current
+ * GPU with garbage on `stream`, as an aborted launch might leave them.  The launches that follow
+ * must run at their usual speed (they restart the counters they use); results never depended on
+ * the counters in the first place.
+ */
+int fa_debug_scribble_meeting_counters(fa_stream_t stream);
+
+/*
  * One whole synchronous round over K client ROWS of one layout: fa_reduce_opt over the weighted
  * fp32 entries (x[k] = start of client k's weighted segment, n floats) plus the plain mean --
  * fa_mean_f32 / fa_mean_i64 / fa_mean_i32 below -- of every segment listed in `means`, found
@@ -150,8 +175,10 @@ int fa_round(const float* const* x, const double* w, int K, float* g, float* m, 
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Same arithmetic, arguments and results as fa_reduce_opt, except that the carry workspace a
  * round of K > FA_KCHUNK clients needs (when step_out is NULL) is not passed in: it is a
- * library-owned array of FA_STATIC_WS_FLOATS floats (128 MiB) that every GPU the library runs
- * on holds from its first use until the process ends.  The call allocates and frees nothing.
+ * library-owned array of FA_STATIC_WS_FLOATS floats (128 MiB) that every GPU holds from the
+ * moment the library's code object is loaded on it until the process ends -- in every process
+ * that loads the library, whether it ever calls this entry point or not.  The call allocates
+ * and frees nothing.
  * K > FA_KCHUNK with step_out == NULL and n > FA_STATIC_WS_FLOATS returns FA_ERR_TOO_LARGE
  * before anything is enqueued.  All calls on one GPU share that GPU's array (its contents are
  * whatever the last call left; every launch writes its part before reading it, so nothing has

@@ -66,7 +66,7 @@ def _reduce_opt64(xs, w, g, m, v, opt, lr, beta1, beta2, tau):
 
 
 def reduce_opt(x, w, g, m=None, v=None, opt="none", lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
-               step_out=None, step_ws=None, n=None):
+               step_out=None, step_ws=None, n=None, persistent=True):
     n = g.numel() if n is None else n
     if g.dtype == torch.float64:
         return _reduce_opt64(_rows(x, n, np.float64), w, _np(g, n), _np(m, n), _np(v, n), opt, lr,
@@ -101,3 +101,11 @@ def mean(x, g, n=None):
         out[...] = acc / np.float64(len(x))
         return
     OC.mean(_rows(x, n, out.dtype.type), out)
+
+
+_MIX_MODES = {"replace": 0, "convex": 1, "subtract": 2, "convex_one": 3, "sum_add": 4, "sum_set": 5}
+
+
+def weighted_mix(x, w, g, mode, coeff=0.0, acc_ws=None, n=None):
+    n = g.numel() if n is None else n
+    OC.weighted_mix(_rows(x, n), w, _np(g, n), _MIX_MODES[mode], coeff)

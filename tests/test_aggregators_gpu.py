@@ -217,6 +217,32 @@ def test_staging_on_arrival_gives_the_same_round():
             assert torch.equal(got[k], want[k]), (r, k)
 
 
+@pytest.mark.parametrize("second", ["same_client", "other_client_staged", "other_client_plain"])
+@pytest.mark.parametrize("big", [False, True])
+def test_a_client_staged_twice_keeps_every_row_apart(second, big):
+    """stage(A, m1), stage(A, m2), then a round of {A: m2, B}: A's second message takes a row of
+    its own (its first row is abandoned), so B's upload cannot land on it; the round equals the
+    un-staged one bit for bit.  `big`: a vector long enough for the fold-on-arrival path."""
+    import appfl_amd.aggregator as A
+    spec = ({"w": ((4_600_003,), "f32"), "steps": ((3,), "i64")} if big else S.RAGGED)
+    cfg = dict(S.HP["FedAvgMAggregator"], num_clients=2)
+    plain, staged = A.FedAvgMAggregator(None, cfg, None), A.FedAvgMAggregator(None, cfg, None)
+    for r in range(2):
+        m1 = S.make_state(spec, seed=300 + 10 * r)
+        m2 = S.make_state(spec, seed=301 + 10 * r)
+        mb = S.make_state(spec, seed=302 + 10 * r)
+        want = plain.aggregate({"A": m2, "B": mb})
+        staged.stage("A", m1)
+        staged.stage("A", m2)
+        if second == "other_client_staged":
+            staged.stage("B", mb)
+        elif second == "same_client":
+            staged.stage("A", m2)
+        got = staged.aggregate({"A": m2, "B": mb})
+        for k in want:
+            assert torch.equal(got[k], want[k]), (r, k)
+
+
 @pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedAvgMAggregator", "FedYogiAggregator"])
 def test_round_after_the_last_arrival_runs_as_a_pipeline_over_its_windows(cls, monkeypatch):
     """Every client staged on arrival and a model long enough: `aggregate` folds the stretch each

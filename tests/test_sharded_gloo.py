@@ -254,3 +254,244 @@ def test_two_ranks_with_float64_entries_kept_whole_on_every_rank(tmp_path):
         for k in want:
             w = want[k].numpy() if isinstance(want[k], torch.Tensor) else want[k]
             assert got[r][k].dtype == w.dtype and got[r][k].tobytes() == w.tobytes(), (r, k)
+
+
+# -- whole-update mode at the state-dict level ----------------------------------------------------
+
+def _close(got, want, rtol):
+    """Within rtol of the tensor's scale where the expected value is finite; the same inf / nan
+    elsewhere (the toy states hold values whose squares overflow fp32)."""
+    fin = np.isfinite(want)
+    if not np.array_equal(np.isfinite(got), fin):
+        return False
+    if not np.array_equal(np.isnan(got), np.isnan(want)) or not np.array_equal(got[np.isinf(want)], want[np.isinf(want)]):
+        return False
+    # the toy states also hold a few finite values around 1e28-1e30 whose terms nearly cancel: they
+    # are compared on their own (1e-4 of their magnitude), so that they do not set the scale
+    big = fin & (np.abs(want) > 1e10)
+    if big.any() and not np.all(np.abs(got[big] - want[big]) <= 1e-4 * np.abs(want[big])):
+        return False
+    fin = fin & ~big
+    if not fin.any():
+        return True
+    scale = max(float(np.max(np.abs(want[fin]))), 1e-30)
+    return float(np.max(np.abs(got[fin] - want[fin]))) <= rtol * scale
+
+
+WHOLE_ROUNDS = [2, 5, 3, 4]
+
+
+def _whole_clients(r, K):
+    import scenarios as S
+    local = {c: S.make_state(S.TOY, seed=1700 + 10 * r + c) for c in range(K)}
+    if r == 1:
+        del local[2]["fc.weight"]            # a client lacking a weighted entry
+    return local
+
+
+def _whole_worker(rank, world, port, alg, with_model, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode="sample_size")
+        agg = ShardedFedAvgAggregator(S.ToyModel() if with_model else None, cfg, None, algorithm=alg,
+                                      device="cpu", backend=cpu_backend, pieces=2, mode="whole")
+        for c in range(5):
+            if c != 3:                              # one client without a recorded sample size
+                agg.set_client_sample_size(c, 4 + 3 * c)
+        recs = []
+        for r, K in enumerate(WHOLE_ROUNDS):
+            local = _whole_clients(r, K)
+            mine = {c: local[c] for c in local if c % world == rank}     # client k -> rank k mod R
+            if r in (0, 2):
+                for c, m in mine.items():           # staged on arrival (round 0: before the state exists)
+                    agg.stage(c, m)
+            out_r = agg.aggregate(mine)
+            again = agg.get_parameters()            # local, no collective
+            for k in out_r:
+                assert again[k].numpy().tobytes() == out_r[k].numpy().tobytes(), k
+            recs.append({k: v.numpy().copy() for k, v in out_r.items()})
+            if r == 3:
+                m, v = agg.gather_moments()         # collective accessor of the sharded moments
+                assert (agg.m_vector is m or not m) and (agg.v_vector is v or not v)
+                recs.append({"m/" + k: t.numpy().copy() for k, t in m.items()})
+                recs.append({"v/" + k: t.numpy().copy() for k, t in v.items()})
+        if rank == world - 1:
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,alg,with_model", [(2, "FedAdam", True), (3, "FedAvg", False),
+                                                  (3, "FedYogi", True), (2, "FedAvgM", False)])
+def test_whole_update_mode_of_the_state_dict_aggregator(world, alg, with_model, tmp_path):
+    """Rank r gets only the clients k = r (mod R) of every round (rank 2 of 3 gets none in the
+    2-client round): weighted fp32 entries within 1e-6 of the tensor's scale of the
+    single-process oracle (the reduce-scatter reorders the sum), everything else bit-exact."""
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_whole_worker, args=(world, _free_port(), alg, with_model, out), nprocs=world, join=True)
+    got = list(np.load(out, allow_pickle=True))
+    cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode="sample_size")
+    model = S.ToyModel() if with_model else None
+    ora = OA.ORACLES[alg + "Aggregator"](model, cfg, None)
+    for c in range(5):
+        if c != 3:
+            ora.set_client_sample_size(c, 4 + 3 * c)
+    params = None if model is None else {n for n, _ in model.named_parameters()}
+    i = 0
+    for r, K in enumerate(WHOLE_ROUNDS):
+        want = ora.aggregate(_whole_clients(r, K))
+        rec = got[i]
+        i += 1
+        assert list(rec) == list(want)
+        for k in want:
+            w = np.asarray(want[k])
+            assert rec[k].dtype == w.dtype and rec[k].shape == w.shape, k
+            weighted = w.dtype == np.float32 and (params is None or k in params)
+            if weighted:
+                assert _close(rec[k], w, 1e-6), (r, k)
+            else:
+                assert rec[k].tobytes() == w.tobytes(), (r, k)
+    if alg != "FedAvg":
+        moments = [getattr(ora, "m_vector", {}), ora.v_vector]
+        for tag, want in zip("mv", moments):
+            rec = got[i]
+            i += 1
+            assert sorted(rec) == sorted(tag + "/" + k for k in want)
+            for k in want:
+                assert _close(rec[tag + "/" + k], want[k], 2e-6), (tag, k)
+
+
+def _holes_worker(rank, world, port, out):
+    """The reference-visible behaviour beside the fused round, sliced mode: compute_steps,
+    m_vector / v_vector, a subclass overriding compute_steps, streamed rounds, flat payloads."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        recs = {}
+        cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="equal")
+        agg = ShardedFedAvgAggregator(S.ToyModel(), cfg, None, algorithm="FedAdam", device="cpu",
+                                      backend=cpu_backend, pieces=2)
+        local = {c: S.make_state(S.TOY, seed=2100 + c) for c in range(3)}
+        recs["round0"] = {k: v.numpy().copy() for k, v in agg.aggregate(local).items()}
+        if world > 1:
+            with pytest.raises(RuntimeError):
+                agg.m_vector                        # sharded: needs the collective accessor first
+        m, v = agg.gather_moments()
+        recs["m"] = {k: t.numpy().copy() for k, t in m.items()}
+        recs["v"] = {k: t.numpy().copy() for k, t in agg.v_vector.items()}
+        local = {c: S.make_state(S.TOY, seed=2200 + c) for c in range(4)}
+        agg.compute_steps(local)                    # collective; leaves the step, moments updated
+        recs["step"] = {k: t.numpy().copy() for k, t in agg.step.items()}
+
+        class Halved(ShardedFedAvgAggregator):      # a user subclass post-processing the step
+            def compute_steps(self, local_models):
+                super().compute_steps(local_models)
+                for t in self.step.values():
+                    t.mul_(0.5)
+        cfg2 = dict(S.HP["FedAvgMAggregator"])
+        sub = Halved(None, cfg2, None, algorithm="FedAvgM", device="cpu", backend=cpu_backend, pieces=3)
+        for r in range(2):
+            local = {c: S.make_state(S.TOY, seed=2300 + 10 * r + c) for c in range(3)}
+            recs[f"halved{r}"] = {k: v.numpy().copy() for k, v in sub.aggregate(local).items()}
+
+        # streamed rounds: chunk by chunk, then a whole round on the same state
+        st = ShardedFedAvgAggregator(None, {}, None, device="cpu", backend=cpu_backend, pieces=2)
+        chunks = S.chunk_keys_by_size(S.TOY, 600)
+        for r in range(2):
+            states = {c: S.make_state(S.TOY, seed=2400 + 10 * r + c) for c in range(3)}
+            if r == 1:
+                recs["streamed_whole"] = {k: v.numpy().copy() for k, v in st.aggregate(
+                    {c: S.make_state(S.TOY, seed=2450 + c) for c in range(2)}).items()}
+            for ci, keys in enumerate(chunks):
+                o = st.aggregate({c: {k: states[c][k].clone() for k in keys} for c in states},
+                                 _chunk_idx={c: ci for c in states},
+                                 _total_chunks={c: len(chunks) for c in states},
+                                 _chunk_keys={c: list(keys) for c in states})
+                recs[f"streamed{r}.{ci}"] = {k: v.numpy().copy() for k, v in o.items()}
+        recs["streamed_final"] = {k: v.numpy().copy() for k, v in st.get_parameters().items()}
+
+        # flat secure-aggregation payloads: replicated on every rank
+        sec = ShardedFedAvgAggregator(None, {"use_secure_agg": True, "client_weights_mode": "sample_size"},
+                                      None, device="cpu", backend=cpu_backend)
+        names = [n for n, (_, kind) in S.TOY.items() if kind == "f32"]
+        for r in range(2):
+            payload = {}
+            for c in range(3):
+                sd = S.make_state(S.TOY, seed=2500 + 10 * r + c, gradient=True, scale=0.01)
+                payload[c] = {"type": "masked_update_flat",
+                              "flat": torch.cat([sd[n].reshape(-1) for n in names]),
+                              "shapes": [(n, tuple(sd[n].shape)) for n in names], "num_examples": 5 + c}
+            recs[f"secure{r}"] = {k: v.numpy().copy() for k, v in sec.aggregate(payload).items()}
+        if rank == world - 1:
+            np.save(out, np.array([recs], dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_class_keeps_the_reference_visible_behaviour(world, tmp_path):
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_holes_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out, allow_pickle=True)[0]
+
+    def same(rec, want, what):
+        assert list(rec) == list(want), what
+        for k in want:
+            w = np.asarray(want[k])
+            assert rec[k].dtype == w.dtype and rec[k].tobytes() == w.tobytes(), (what, k)
+
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="equal")
+    ora = OA.OracleFedAdam(S.ToyModel(), cfg, None)
+    same(got["round0"], ora.aggregate({c: S.make_state(S.TOY, seed=2100 + c) for c in range(3)}), "round0")
+    same(got["m"], ora.m_vector, "m")
+    same(got["v"], ora.v_vector, "v")
+    ora.compute_steps({c: {k: v.numpy() for k, v in S.make_state(S.TOY, seed=2200 + c).items()}
+                       for c in range(4)})
+    same(got["step"], ora.step, "step")
+
+    class HalvedOracle(OA.OracleFedAvgM):
+        def compute_steps(self, local_models):
+            super().compute_steps(local_models)
+            for k in self.step:
+                self.step[k] = self.step[k] * np.float32(0.5)
+    sub = HalvedOracle(None, dict(S.HP["FedAvgMAggregator"]), None)
+    for r in range(2):
+        same(got[f"halved{r}"], sub.aggregate({c: S.make_state(S.TOY, seed=2300 + 10 * r + c)
+                                               for c in range(3)}), f"halved{r}")
+
+    st = OA.OracleFedAvg(None, {}, None)
+    chunks = S.chunk_keys_by_size(S.TOY, 600)
+    for r in range(2):
+        states = {c: S.make_state(S.TOY, seed=2400 + 10 * r + c) for c in range(3)}
+        if r == 1:
+            same(got["streamed_whole"], st.aggregate({c: S.make_state(S.TOY, seed=2450 + c)
+                                                      for c in range(2)}), "streamed_whole")
+        for ci, keys in enumerate(chunks):
+            o = st.aggregate({c: {k: states[c][k].clone() for k in keys} for c in states},
+                             _chunk_idx={c: ci for c in states},
+                             _total_chunks={c: len(chunks) for c in states},
+                             _chunk_keys={c: list(keys) for c in states})
+            same(got[f"streamed{r}.{ci}"], o, f"streamed{r}.{ci}")
+    same(got["streamed_final"], st.get_parameters(), "streamed_final")
+
+    sec = OA.OracleFedAvg(None, {"use_secure_agg": True, "client_weights_mode": "sample_size"}, None)
+    names = [n for n, (_, kind) in S.TOY.items() if kind == "f32"]
+    for r in range(2):
+        payload = {}
+        for c in range(3):
+            sd = S.make_state(S.TOY, seed=2500 + 10 * r + c, gradient=True, scale=0.01)
+            payload[c] = {"type": "masked_update_flat",
+                          "flat": torch.cat([sd[n].reshape(-1) for n in names]),
+                          "shapes": [(n, tuple(sd[n].shape)) for n in names], "num_examples": 5 + c}
+        same(got[f"secure{r}"], sec.aggregate(payload), f"secure{r}")
