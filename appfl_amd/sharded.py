@@ -123,12 +123,21 @@ def gather_rows(smap: ShardMap, g: torch.Tensor, out: torch.Tensor, group=None,
     return works
 
 
-# Whether the rounds of a pipelined sharded round (kernel on block row p+1 beside the all-gather
-# of row p) may take the one-block-per-CU persistent kernels.  Measured on one MI355X with a
-# device-to-device copy kernel standing in for RCCL's gather on a second stream
-# (tools/coresidency_probe.py; the log sits with the profiles): see the note at its definition's
-# use below.  A per-call routing flag of the C ABI (FA_ROUTE_NO_PERSISTENT), not process state.
-PERSISTENT_BESIDE_GATHER = False
+def persistent_beside_gather(opt: str) -> bool:
+    """Whether the kernel of block row p+1 may be one of the one-block-per-CU persistent kernels
+    while the all-gather of row p runs on the same GPU.  Measured on one MI355X with a stand-in
+    for RCCL's gather on a second stream (tools/coresidency_probe.py: 8-64 persistent blocks
+    holding 12 / 104 / 264 registers per lane that write one peer's block of the row, at full
+    speed or throttled to a link-bound 5-9 ms).  Beside a register-heavy, long-running stand-in a
+    persistent round runs 1.4-1.6 times as long as alone (its blocks for the CUs the stand-in
+    holds start late), the tile-per-block kernel 1.0-1.1 times.  What counts is when BOTH are
+    done: plain FedAvg rows of 81 M elements x 32 clients end 2-6 % earlier with the
+    tile-per-block kernel (pipeline of four rows 11.4 vs 11.6 ms, 23.5 vs 24.9 ms), but under the
+    two-moment optimizers the tile-per-block kernel is 11 % slower to begin with and the persistent
+    one still ends first or level (81 M x 32: 12.0 vs 13.7 ms and 25.7 vs 26.3 ms; 25.6 M x 64:
+    6.1 vs 6.8 ms and 9.2 vs 10.6 ms).  Hence: keep FedAvg / FedAvgM rounds off the persistent
+    kernels beside a gather, leave FedAdam / FedYogi / FedAdagrad on the default routing."""
+    return opt in ("adam", "yogi", "adagrad")
 
 
 def round_gather_pipelined(ops, smap: ShardMap, x: Sequence, w: Sequence[float], g, m, v, opt: str,
@@ -140,11 +149,12 @@ def round_gather_pipelined(ops, smap: ShardMap, x: Sequence, w: Sequence[float],
     also for rows in which its own block is empty.  On xGMI the gather of a large model takes
     about as long as the local round, so the pipeline hides whichever is shorter.
     `persistent`: whether the kernels may be the one-block-per-CU ones (default: yes when nothing
-    runs beside them -- one rank or one block row --, else PERSISTENT_BESIDE_GATHER)."""
+    runs beside them -- one rank or one block row --, else `persistent_beside_gather(opt)`; a
+    per-call routing flag of the C ABI, FA_ROUTE_NO_PERSISTENT, not process state)."""
     if out.numel() < smap.P:
         raise ValueError("gather buffer shorter than the padded vector")
     if persistent is None:
-        persistent = PERSISTENT_BESIDE_GATHER or smap.world == 1 or smap.pieces == 1
+        persistent = smap.world == 1 or smap.pieces == 1 or persistent_beside_gather(opt)
     extra = {} if persistent else {"persistent": False}
     works = []
     for p in range(smap.pieces):

@@ -772,3 +772,61 @@ def test_round_resumed_from_a_partial_step(opt, hp, n_step, K, cuts):
         assert_bits(m, m_ref, "m")
     for j, name in enumerate(("mean f32", "mean i64", "mean i32")):
         assert_bits(outs[j], wants[j], name)
+
+
+def test_meeting_counters_heal_and_later_rounds_keep_their_speed():
+    """The persistent kernel's meeting counters are timing-only state that nothing clears between
+    launches.  Garbage left in them (as by an aborted launch), more than 64 phased rounds, and
+    rounds overlapping on two streams must neither change a bit nor slow down the rounds that
+    follow (an unhealed counter costs every block a time-out at every meeting)."""
+    from appfl_amd import ops
+    K, n = 48, 30_000_000                       # 28 tiles per CU: written in phases, with meetings
+    assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
+    d = torch.device("cuda")
+    g0 = torch.empty(n, device=d)
+    ops.synth_fill(g0, 7, scale=0.05)
+    xs = torch.empty((K, n), device=d)
+    for k in range(K):
+        ops.synth_fill(xs[k], 1000 + k, scale=0.01, base=g0)
+    rows, w = list(xs), [1.0 / K] * K
+
+    def timed(g, reps=7):
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.reduce_opt(rows, w, g)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    ref = g0.clone()
+    ops.reduce_opt(rows, w, ref)                # one round from g0: the bits every variant must give
+    base_ms = timed(g0.clone())
+    ops.scribble_meeting_counters()
+    g = g0.clone()
+    ops.reduce_opt(rows, w, g)
+    assert torch.equal(g, ref)
+    healed_ms = timed(g0.clone())
+    assert healed_ms <= 1.15 * base_ms, (base_ms, healed_ms)
+    # > 64 phased rounds, overlapping on two streams (each stream has a counter slot of its own)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ga, gb = g0.clone(), g0.clone()
+    torch.cuda.synchronize()
+    for i in range(80):
+        with torch.cuda.stream(s1):
+            ops.reduce_opt(rows, w, ga)
+        with torch.cuda.stream(s2):
+            ops.reduce_opt(rows, w, gb)
+    torch.cuda.synchronize()
+    assert torch.equal(ga, gb)
+    after_ms = timed(g0.clone())
+    assert after_ms <= 1.15 * base_ms, (base_ms, after_ms)
+    # garbage again, this time found by launches on the side streams
+    ops.scribble_meeting_counters()
+    with torch.cuda.stream(s1):
+        g1 = g0.clone()
+        ops.reduce_opt(rows, w, g1)
+    torch.cuda.synchronize()
+    assert torch.equal(g1, ref)

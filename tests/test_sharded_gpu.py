@@ -182,3 +182,144 @@ def test_two_ranks_on_one_gpu_hip_kernels_with_gloo_collectives(tmp_path):
         OC.reduce_opt(xs, [1.0 / K] * K, gw, m, v, OC.OPT_ADAM, **HP)
     # the second round sums the two ranks' partial steps: fp32 additions reordered
     assert np.max(np.abs(g - gw)) <= 1e-6 * np.max(np.abs(gw))
+
+
+@pytest.mark.parametrize("alg,with_model", [("FedAdam", True), ("FedAvg", False), ("FedAvgM", True)])
+def test_whole_update_mode_single_rank_matches_oracle_bit_for_bit(alg, with_model):
+    """`mode="whole"` on one rank: no collective reorders anything, so the un-fused sequence
+    (partial step, optimizer epilogue, apply, means over the gathered row tails) must give the
+    oracle's bits -- clients staged before the state exists, a client lacking a weighted entry,
+    `get_parameters`, `compute_steps` and the moments included."""
+    import scenarios as S
+    from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+    cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode="sample_size")
+    model = S.ToyModel if with_model else (lambda: None)
+    agg = ShardedFedAvgAggregator(model(), cfg, None, algorithm=alg, pieces=3, mode="whole")
+    ora = OA.ORACLES[alg + "Aggregator"](model(), cfg, None)
+    for a in (agg, ora):
+        for c in range(5):
+            if c != 3:
+                a.set_client_sample_size(c, 4 + 3 * c)
+    for r, K in enumerate([2, 5, 3]):
+        local = {c: S.make_state(S.TOY, seed=1700 + 10 * r + c) for c in range(K)}
+        if r == 1:
+            del local[2]["fc.weight"]
+        if r in (0, 2):
+            for c, m in local.items():
+                agg.stage(c, m)
+        got = agg.aggregate(local)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
+        assert list(got) == list(want)
+        for k in want:
+            assert golden_util.same_bits(got[k].numpy(), np.asarray(want[k])), (r, k)
+    again = agg.get_parameters()
+    for k in got:
+        assert golden_util.same_bits(again[k].numpy(), got[k].numpy()), k
+    local = {c: S.make_state(S.TOY, seed=1800 + c) for c in range(4)}
+    agg.compute_steps(local)
+    ora.compute_steps({c: {k: v.numpy() for k, v in m.items()} for c, m in local.items()})
+    assert sorted(agg.step) == sorted(ora.step)
+    for k, t in ora.step.items():
+        assert golden_util.same_bits(agg.step[k].cpu().numpy(), t), ("step", k)
+    if alg != "FedAvg":
+        m, v = agg.gather_moments()
+        for name, got_d, want_d in (("m", m, getattr(ora, "m_vector", {})), ("v", v, ora.v_vector)):
+            assert sorted(got_d) == sorted(want_d), name
+            for k, t in want_d.items():
+                assert golden_util.same_bits(got_d[k].cpu().numpy(), t), (name, k)
+                assert golden_util.same_bits(getattr(agg, name + "_vector")[k].cpu().numpy(), t), (name, k)
+
+
+def test_sliced_sharded_class_serves_compute_steps_moments_streamed_and_flat_payload_rounds():
+    """What the reference's class exposes beside the fused round, on the HIP kernels (one rank):
+    `compute_steps` + `step`, `m_vector` / `v_vector`, a subclass overriding `compute_steps`,
+    streamed rounds sharing the state with whole rounds, flat secure-aggregation payloads."""
+    import scenarios as S
+    from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+
+    def same(got, want, what):
+        assert list(got) == list(want), what
+        for k in want:
+            g = got[k].cpu().numpy() if isinstance(got[k], torch.Tensor) else got[k]
+            assert golden_util.same_bits(g, np.asarray(want[k])), (what, k)
+
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="equal")
+    agg = ShardedFedAvgAggregator(S.ToyModel(), cfg, None, algorithm="FedAdam", pieces=2)
+    ora = OA.OracleFedAdam(S.ToyModel(), cfg, None)
+    local = {c: S.make_state(S.TOY, seed=2100 + c) for c in range(3)}
+    same(agg.aggregate(local), ora.aggregate(local), "round0")
+    same(agg.m_vector, ora.m_vector, "m")
+    same(agg.v_vector, ora.v_vector, "v")
+    local = {c: S.make_state(S.TOY, seed=2200 + c) for c in range(4)}
+    agg.compute_steps(local)
+    ora.compute_steps({c: {k: v.numpy() for k, v in m.items()} for c, m in local.items()})
+    same(agg.step, ora.step, "step")
+
+    class Halved(ShardedFedAvgAggregator):
+        def compute_steps(self, local_models):
+            super().compute_steps(local_models)
+            for t in self.step.values():
+                t.mul_(0.5)
+
+    class HalvedOracle(OA.OracleFedAvgM):
+        def compute_steps(self, local_models):
+            super().compute_steps(local_models)
+            for k in self.step:
+                self.step[k] = self.step[k] * np.float32(0.5)
+    sub = Halved(None, dict(S.HP["FedAvgMAggregator"]), None, algorithm="FedAvgM", pieces=3)
+    sub_o = HalvedOracle(None, dict(S.HP["FedAvgMAggregator"]), None)
+    for r in range(2):
+        local = {c: S.make_state(S.TOY, seed=2300 + 10 * r + c) for c in range(3)}
+        same(sub.aggregate(local), sub_o.aggregate(local), f"halved{r}")
+
+    st, st_o = ShardedFedAvgAggregator(None, {}, None, pieces=2), OA.OracleFedAvg(None, {}, None)
+    chunks = S.chunk_keys_by_size(S.TOY, 600)
+    for r in range(2):
+        states = {c: S.make_state(S.TOY, seed=2400 + 10 * r + c) for c in range(3)}
+        if r == 1:
+            whole = {c: S.make_state(S.TOY, seed=2450 + c) for c in range(2)}
+            same(st.aggregate(whole), st_o.aggregate(whole), "streamed_whole")
+        for ci, keys in enumerate(chunks):
+            kw = dict(_chunk_idx={c: ci for c in states}, _total_chunks={c: len(chunks) for c in states},
+                      _chunk_keys={c: list(keys) for c in states})
+            part = {c: {k: states[c][k].clone() for k in keys} for c in states}
+            same(st.aggregate(part, **kw), st_o.aggregate(part, **kw), f"streamed{r}.{ci}")
+    same(st.get_parameters(), st_o.get_parameters(), "streamed_final")
+
+    scfg = {"use_secure_agg": True, "client_weights_mode": "sample_size"}
+    sec, sec_o = ShardedFedAvgAggregator(None, scfg, None), OA.OracleFedAvg(None, scfg, None)
+    names = [n for n, (_, kind) in S.TOY.items() if kind == "f32"]
+    for r in range(2):
+        payload = {}
+        for c in range(3):
+            sd = S.make_state(S.TOY, seed=2500 + 10 * r + c, gradient=True, scale=0.01)
+            payload[c] = {"type": "masked_update_flat",
+                          "flat": torch.cat([sd[n].reshape(-1) for n in names]),
+                          "shapes": [(n, tuple(sd[n].shape)) for n in names], "num_examples": 5 + c}
+        same(sec.aggregate(payload), sec_o.aggregate(payload), f"secure{r}")
+
+
+@pytest.mark.parametrize("opt,K,n", [("none", 48, 21_000_003), ("none", 8, 80_000_004), ("adam", 48, 9_000_001),
+                                     ("avgm", 64, 5_000_000)])
+def test_rounds_kept_off_the_persistent_kernels_give_the_same_bits(opt, K, n):
+    """fa_reduce_opt_ex with FA_ROUTE_NO_PERSISTENT (what the sharded rounds pass beside a running
+    gather): shapes the default routing sends to a persistent kernel must come out bit-identical
+    from the tile-per-block kernel."""
+    from appfl_amd import ops
+    assert ops.reduce_kernel_name(K, n, opt) != "reduce_kernel"
+    dev = torch.device("cuda")
+    g0 = torch.empty(n, device=dev)
+    ops.synth_fill(g0, 7, scale=0.05)
+    xs = torch.empty((K, n), device=dev)
+    for k in range(K):
+        ops.synth_fill(xs[k], 1000 + k, scale=0.01, base=g0)
+    w = [(k + 1) / (K * (K + 1) / 2) for k in range(K)]
+    outs = []
+    for persistent in (True, False):
+        g, m, v = g0.clone(), torch.zeros(n, device=dev), torch.full((n,), 1e-6, device=dev)
+        for _ in range(2):
+            ops.reduce_opt(list(xs), w, g, m if opt in ("adam",) else None, v if opt != "none" else None,
+                           opt, persistent=persistent, **HP)
+        outs.append((g, m, v))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
