@@ -113,7 +113,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._folded: Optional[dict] = None
         self._folded_round: Optional[dict] = None     # ... as `_stage` found it for the round being aggregated
         self._fold_flat: Optional[torch.Tensor] = None   # the partial step of the clients folded on arrival
-        self._round_plan = None                  # marshalled arguments of the last fused round (ops.RoundPlan)
+        self._round_plans: Dict[tuple, Any] = {}  # marshalled arguments of recent fused rounds (ops.RoundPlan)
         self._init_lock()
 
     # -- attributes the reference exposes -------------------------------------------------------
@@ -472,16 +472,16 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 # a steady federation repeats the same call: keep its marshalled arguments
                 key = (K, self._slab.slab.data_ptr(), tuple(self._row_indices(K)), tuple(weights),
                        self._flats["f32"].data_ptr(), id(self._m), id(self._v), tuple(hyper.values()))
-                plan = self._round_plan
-                if plan is None or plan.key != key:
-                    plan = None
+                plan = self._round_plans.get(key)
             if plan is None:
                 means = [(lay.seg_byte[cls], out, lay.count[cls])
                          for cls, out in ((MEAN_F32, self._flats["f32"][n_step:]),
                                           (MEAN_I64, self._flats["i64"]), (MEAN_I32, self._flats["i32"]))
                          if lay.count[cls]]
                 if ws is None and hasattr(self._ops, "RoundPlan"):
-                    plan = self._round_plan = self._ops.RoundPlan(
+                    if len(self._round_plans) >= 16:
+                        self._round_plans.clear()
+                    plan = self._round_plans[key] = self._ops.RoundPlan(
                         self._rows(K, 0), weights, self._flats["f32"], self._m, self._v, self._OPT,
                         n=n_step, means=means, key=key, **hyper)
             if events:

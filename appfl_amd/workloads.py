@@ -125,6 +125,16 @@ WORKLOADS: Dict[str, Dict] = {
     # ADMM server updates: K clients' primal, dual and previous-primal rows resident in HBM
     "resnet50_iiadmm_k16": {"table": lambda: resnet(50), "cls": "IIADMMAggregator", "K": 16},
     "resnet50_iceadmm_k16": {"table": lambda: resnet(50), "cls": "ICEADMMAggregator", "K": 16},
+    # one arrival of a FedBuff buffer of each kind (bytes per parameter: the first arrival of a
+    # buffer reads x, g and writes the buffer = 12; a middle one also reads the buffer = 16; the
+    # flushing one also writes g = 20)
+    "vitb16_fedbuff_first": {"table": vit_b_16, "cls": "FedBuffAggregator", "K": 16, "kind": "first"},
+    "vitb16_fedbuff_middle": {"table": vit_b_16, "cls": "FedBuffAggregator", "K": 16, "kind": "middle"},
+    "vitb16_fedbuff_flush": {"table": vit_b_16, "cls": "FedBuffAggregator", "K": 16, "kind": "flush"},
+    # FedCompass group mix g = (1 - sum w) g + sum w_k x_k and FedQueue replace g = sum w_k x_k
+    # (fa_weighted_mix) over K rows of the model's parameters
+    "vitb16_fedcompass_group_k8": {"table": vit_b_16, "cls": "FedCompassAggregator", "K": 8, "mode": "convex"},
+    "vitb16_fedqueue_replace_k16": {"table": vit_b_16, "cls": "FedQueueAggregator", "K": 16, "mode": "replace"},
     "flat162m_fedavg_k32": {"table": lambda: flat(162_500_000), "cls": "FedAvgAggregator", "K": 32},
     # the whole 1.3 B-parameter vector on ONE GPU: 166 GB of client rows in HBM
     "flat1300m_fedavg_k32": {"table": lambda: flat(1_300_000_000), "cls": "FedAvgAggregator", "K": 32},

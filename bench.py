@@ -46,8 +46,14 @@ DEFAULT_WORKLOAD = "resnet18_fedavg_k100"
 SHARDED_WORKLOAD = "flat1300m_fedavg_k32"
 NORTH_STAR_WORKLOAD = "resnet50_fedadam_k64"
 SHARDED_EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64"]
-EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "flat162m_fedavg_k32",
-                   "vitb16_fedasync", "vitb16_fedbuff_k16", "resnet50_iiadmm_k16", "resnet50_iceadmm_k16"]
+EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "resnet50_fedavgm_k64",
+                   "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
+                   "vitb16_fedbuff_first", "vitb16_fedbuff_middle", "vitb16_fedbuff_flush",
+                   "vitb16_fedcompass_group_k8", "vitb16_fedqueue_replace_k16"]
+# workloads also timed with COLD state vectors (see SyncBench): the headline, the north-star
+# target and the long flat vector
+COLD_WORKLOADS = {"resnet18_fedavg_k100", "resnet50_fedadam_k64", "flat162m_fedavg_k32"}
+INFINITY_CACHE_BYTES = 256 << 20
 _OPT_OF = {"FedAvgAggregator": "none", "FedAvgMAggregator": "avgm", "FedAdamAggregator": "adam",
            "FedYogiAggregator": "yogi", "FedAdagradAggregator": "adagrad"}
 STATE_VECTORS = {"none": 2, "avgm": 4, "adam": 6, "yogi": 6, "adagrad": 6}  # g/m/v reads + writes
@@ -78,9 +84,15 @@ def template_state(rows):
 
 
 class SyncBench:
-    """FedAvg-family workload: K synthetic client rows in the device slab, one round per step."""
+    """FedAvg-family workload: K synthetic client rows in the device slab, one round per step.
 
-    def __init__(self, wl, rank):
+    In a benchmark loop the state vectors (g, and m / v under the optimizers) are the same buffers
+    every step, and vectors of up to 256 MB can stay in the Infinity Cache from one step to the
+    next, which a real round -- gigabytes of client uploads in between -- would not see.
+    `cold_sets` > 1 rotates that many independent sets of state vectors (together at least twice
+    the cache), so that no step reads state an earlier step left in the cache."""
+
+    def __init__(self, wl, rank, cold_sets=0):
         import appfl_amd.aggregator as A
         from appfl_amd import ops, workloads as W
         from appfl_amd.layout import MEAN_I32, MEAN_I64, STEP
@@ -106,8 +118,25 @@ class SyncBench:
         self.alg_bytes = 4 * (self.K + STATE_VECTORS[self.opt]) * self.n_step
         self.client_bytes = self.K * self.payload
         self.result_numel = lay.n_f32
+        self.sets, self.turn = [], 0
+        if cold_sets > 1:
+            self.agg._ensure_moments()
+            first = (self.agg._flats["f32"], self.agg._m, self.agg._v)
+            self.sets = [first] + [tuple(None if t is None else t.clone() for t in first)
+                                   for _ in range(cold_sets - 1)]
+
+    @staticmethod
+    def cold_sets_for(wl):
+        """Sets of state vectors whose total is at least twice the Infinity Cache (3 at least)."""
+        from appfl_amd import workloads as W
+        n = W.numel([r for r in wl["table"]() if r[2] == torch.float32])
+        per_set = 4 * n * (STATE_VECTORS[_OPT_OF[wl["cls"]]] // 2)
+        return max(3, min(16, -(-2 * INFINITY_CACHE_BYTES // per_set)))
 
     def step(self, events=None):
+        if self.sets:
+            self.turn = (self.turn + 1) % len(self.sets)
+            self.agg._flats["f32"], self.agg._m, self.agg._v = self.sets[self.turn]
         self.agg._launch_round(self.K, self.weights, True, events)
 
     def result(self):
@@ -137,10 +166,15 @@ class AsyncBench:
                        scale=0.01, base=g, n=lay.n_f32)
         self.K = wl["K"]
         self.i = 0
+        self.kind = wl.get("kind")          # FedBuff: time only first / middle / flushing arrivals
         self.kernel = "buff_accum_kernel" if self.buff else "async_mix_kernel"
         # x, g read + g write; FedBuff: x, g, step read + step write -- the first arrival of a
-        # buffer skips the step read and the flushing one adds the g write, so 16 on average
-        self.alg_bytes = 16 * self.n_step if self.buff else 12 * self.n_step
+        # buffer skips the step read (12) and the flushing one adds the g write (20), so 16 on
+        # average over a buffer
+        per = {"first": 12, "middle": 16, "flush": 20}.get(self.kind, 16) if self.buff else 12
+        self.alg_bytes = per * self.n_step
+        if self.kind:
+            self.kernel += "<%s>" % self.kind
         self.client_bytes = 4 * lay.n_f32
         self.result_numel = lay.n_f32
 
@@ -152,6 +186,8 @@ class AsyncBench:
             events[0].record()
         if self.buff:
             pos = self.i % self.K
+            if self.kind:
+                pos = {"first": 0, "middle": 1, "flush": self.K - 1}[self.kind]
             self.agg._launch_arrival(alpha_t, pos == 0, pos == self.K - 1)
         else:
             self.agg._launch_arrival(alpha_t)
@@ -161,6 +197,45 @@ class AsyncBench:
 
     def result(self):
         return self.agg._flats["f32"][:self.result_numel]
+
+
+class MixBench:
+    """FedCompass / FedQueue combine (fa_weighted_mix) over K rows of the model's parameters
+    resident in HBM: `convex` g = (1 - sum w) g + sum w_k x_k (a FedCompass group arrival,
+    fedcompass_aggregator.py:152-338) or `replace` g = sum w_k x_k (FedQueue,
+    fedqueue_aggregator.py:75-131).  One call per step."""
+
+    def __init__(self, wl, rank):
+        from appfl_amd import ops, workloads as W
+        self.ops = ops
+        rows = wl["table"]()
+        n = self.n_step = W.numel([r for r in rows if r[2] == torch.float32], params_only=True)
+        K = self.K = wl["K"]
+        self.mode = wl["mode"]
+        stride = (n + 63) // 64 * 64
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.g = torch.empty(n, dtype=torch.float32, device=dev)
+        ops.synth_fill(self.g, 7 + 1000003 * rank, scale=0.05)
+        self.slab = torch.empty((K, stride), dtype=torch.float32, device=dev)
+        for k in range(K):
+            ops.synth_fill(self.slab[k], 1000 + k, scale=0.01, base=self.g, n=n)
+        self.rows = [self.slab[k] for k in range(K)]
+        self.weights = [0.5 / K] * K if self.mode == "convex" else [1.0 / K] * K
+        self.kernel = "mix_kernel<%s>" % self.mode
+        # K client reads + g written (replace) or read and written (convex)
+        self.alg_bytes = 4 * (K + (2 if self.mode == "convex" else 1)) * n
+        self.client_bytes = 4 * K * n
+        self.result_numel = n
+
+    def step(self, events=None):
+        if events:
+            events[0].record()
+        self.ops.weighted_mix(self.rows, self.weights, self.g, self.mode, coeff=0.5, n=self.n_step)
+        if events:
+            events[1].record()
+
+    def result(self):
+        return self.g
 
 
 class AdmmBench:
@@ -214,6 +289,8 @@ def bench_class(wl):
         return AsyncBench
     if wl["cls"] in ("IIADMMAggregator", "ICEADMMAggregator"):
         return AdmmBench
+    if wl["cls"] in ("FedCompassAggregator", "FedQueueAggregator"):
+        return MixBench
     return SyncBench
 
 
@@ -369,6 +446,82 @@ def end_to_end(wl, rounds=4, arrivals=7):
                     "median of rounds 2.."}
 
 
+def end_to_end_wire(wl, rounds=3):
+    """The round as a communicator sees it, from wire bytes to wire bytes: K `torch.save`
+    payloads (comm/mpi/serializer.py:46-50, comm/grpc/utils.py:20-24) -> new global model as
+    `torch.save`-compatible bytes.  `device_wire_path`: `stage_bytes` per arrival (tensors read in
+    place from the payload and packed straight into the pinned row), `aggregate`,
+    `wire.model_to_bytes`.  `torch_io_path`: what the unmodified server does around the same
+    aggregator -- `torch.load(map_location="cpu")` per arrival (agent/server.py:505-513),
+    `aggregate`, `torch.save` (comm/mpi/serializer.py:46-50).  Host-inclusive; never `value`."""
+    import io
+
+    import appfl_amd.aggregator as A
+    from appfl_amd import ops, wire, workloads as W
+
+    rows, K = wl["table"](), wl["K"]
+    nf = W.numel([r for r in rows if r[2] == torch.float32])
+    base = torch.empty(nf, dtype=torch.float32, device="cuda")
+    ops.synth_fill(base, 7, scale=0.05)
+    buf = torch.empty_like(base)
+    payloads = []
+    for k in range(K):
+        ops.synth_fill(buf, 1000 + k, scale=0.01, base=base)
+        flat, state, off = buf.cpu(), {}, 0
+        for name, shape, dtype, _ in rows:
+            n = 1
+            for d in shape:
+                n *= d
+            if dtype == torch.float32:
+                state[name] = flat[off:off + n].view(shape)
+                off += n
+            else:
+                state[name] = torch.full(shape, 3, dtype=dtype)
+        b = io.BytesIO()
+        torch.save(state, b)
+        payloads.append(b.getvalue())
+    del base, buf
+    nbytes = sum(len(p) for p in payloads)
+
+    def device_path(agg):
+        t0 = time.perf_counter()
+        models = {}
+        for k, p in enumerate(payloads[:-1]):
+            models[k] = agg.stage_bytes(k, p)
+        t1 = time.perf_counter()
+        models[K - 1] = agg.stage_bytes(K - 1, payloads[-1])
+        out = agg.aggregate(models)
+        reply = wire.model_to_bytes(out)
+        t2 = time.perf_counter()
+        return t2 - t0, t2 - t1, len(reply)
+
+    def torch_path(agg):
+        t0 = time.perf_counter()
+        models = {}
+        for k, p in enumerate(payloads[:-1]):
+            models[k] = torch.load(io.BytesIO(p), map_location="cpu")
+        t1 = time.perf_counter()
+        models[K - 1] = torch.load(io.BytesIO(payloads[-1]), map_location="cpu")
+        out = agg.aggregate(models)
+        b = io.BytesIO()
+        torch.save(out, b)
+        t2 = time.perf_counter()
+        return t2 - t0, t2 - t1, b.tell()
+
+    res = {}
+    for label, fn in (("device_wire_path", device_path), ("torch_io_path", torch_path)):
+        agg = getattr(A, wl["cls"])(None, dict(W.EXAMPLE_CONFIGS[wl["cls"]], num_clients=K), None)
+        runs = [fn(agg) for _ in range(rounds)]
+        total, last, reply = sorted(runs[1:])[len(runs[1:]) // 2]
+        res[label] = {"ms_per_round": round(total * 1e3, 2), "after_last_arrival_ms": round(last * 1e3, 2),
+                      "value": round(nbytes / total / 1e9, 2), "unit": "GB/s", "reply_bytes": reply}
+        del agg
+        torch.cuda.empty_cache()
+    res["what"] = (f"{K} torch.save payloads ({nbytes} B in all) -> reply bytes; arrivals back to back on one "
+                   "thread, median of rounds 2..")
+    return res
+
+
 class ShardedBench:
     """The flat vector of a FedAvg-family workload dealt to the ranks in blocks; K synthetic
     client rows per rank, generated on the device so that the ranks' blocks are pieces of ONE
@@ -457,6 +610,22 @@ def roofline_of(b, kernel_ms, workload):
             "algorithmic_bytes_per_launch": int(b.alg_bytes)}
 
 
+def measure_cold(wl, name, steps, warmup, barrier):
+    """The same workload with its state vectors rotated over independent sets (cold state: no
+    step re-reads what an earlier one left in the Infinity Cache)."""
+    sets = SyncBench.cold_sets_for(wl)
+    b = SyncBench(wl, 0, cold_sets=sets)
+    elapsed, kernel_ms = time_steps(b.step, steps, max(warmup, sets), barrier, False)
+    r = roofline_of(b, kernel_ms, name)
+    out = {"frac_cold": r["frac"], "kernel_avg_ms_cold": r["kernel_avg_ms"],
+           "kernel_min_ms_cold": r["kernel_min_ms"], "achieved_cold": r["achieved"],
+           "value_cold": round(b.client_bytes * steps / elapsed / 1e9, 2),
+           "ms_per_step_cold": round(elapsed / steps * 1e3, 4), "state_sets": sets}
+    del b
+    torch.cuda.empty_cache()
+    return out
+
+
 def measure_workload(name, steps, warmup, barrier):
     """One extra workload on this GPU: same timing as the headline, its objects freed after."""
     from appfl_amd import workloads as W
@@ -472,6 +641,8 @@ def measure_workload(name, steps, warmup, barrier):
            "achieved": r["achieved"], "frac": r["frac"], "traffic": r["traffic"]}
     del b
     torch.cuda.empty_cache()
+    if name in COLD_WORKLOADS:
+        out.update(measure_cold(wl, name, steps, warmup, barrier))
     return out
 
 
@@ -503,6 +674,15 @@ def measure_sharded(name, wl, world, rank, steps, warmup, barrier, use_dist):
     return out
 
 
+def device_identity(index):
+    """host | GPU uuid | PCI address of device `index` of this process."""
+    import socket
+    p = torch.cuda.get_device_properties(index)
+    pci = "%04x:%02x:%02x" % tuple(int(getattr(p, k, 0) or 0)
+                                   for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return "%s|%s|%s" % (socket.gethostname(), getattr(p, "uuid", ""), pci)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -516,13 +696,24 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # proof that the job really is N ranks on N distinct GPUs: the process group's own size and
+    # every rank's device identity, gathered over the group
+    ranks, devices = 1, [device_identity(local_rank)]
+    if use_dist:
+        ranks = dist.get_world_size()
+        devices = [None] * ranks
+        dist.all_gather_object(devices, device_identity(local_rank))
+        if ranks != a.gpus or len(set(devices)) != ranks:
+            raise SystemExit(f"--gpus {a.gpus}: the process group has {ranks} ranks on "
+                             f"{len(set(devices))} distinct devices: {devices}")
+
     from appfl_amd import workloads as W
     sharded = world > 1 or a.sharded
     name = a.workload or (SHARDED_WORKLOAD if sharded else DEFAULT_WORKLOAD)
     if name not in W.WORKLOADS:
         raise SystemExit(f"unknown workload {name}; choose from {sorted(W.WORKLOADS)}")
     wl = W.WORKLOADS[name]
-    is_async = wl["cls"] in ("FedAsyncAggregator", "FedBuffAggregator", "IIADMMAggregator", "ICEADMMAggregator")
+    is_async = bench_class(wl) is not SyncBench
     if sharded and is_async:
         raise SystemExit("the sharded benchmark takes a FedAvg-family workload")
 
@@ -555,7 +746,8 @@ def main():
                                   "frac": e["roofline"]["frac"]})
         if rank == 0:
             out = {
-                "metric": METRIC, **m["forms"]["allgather_pipelined"], "n_gpus": world, "steps": a.steps,
+                "metric": METRIC, **m["forms"]["allgather_pipelined"], "n_gpus": world, "ranks": ranks,
+                "devices": devices, "steps": a.steps,
                 "warmup": a.warmup, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": name, "aggregator": wl["cls"], "clients": wl["K"], **m["config"],
@@ -581,6 +773,8 @@ def main():
             "value": round(world * b.client_bytes * a.steps / elapsed / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world,
+            "ranks": ranks,
+            "devices": devices,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
@@ -596,6 +790,12 @@ def main():
         }
         del b
         torch.cuda.empty_cache()
+        if name in COLD_WORKLOADS or (bench_class(wl) is SyncBench and not a.only):
+            cold = measure_cold(wl, name, a.steps, a.warmup, barrier)
+            out["roofline"].update({k: cold[k] for k in ("frac_cold", "kernel_avg_ms_cold",
+                                                           "kernel_min_ms_cold", "achieved_cold",
+                                                           "state_sets")})
+            out["value_cold"], out["ms_per_step_cold"] = cold["value_cold"], cold["ms_per_step_cold"]
         if not a.only:
             extra = []
             for other in EXTRA_WORKLOADS:
@@ -605,7 +805,9 @@ def main():
             target = next((w for w in extra if w["workload"] == NORTH_STAR_WORKLOAD), None)
             if target is not None:
                 out["north_star_target"] = {"workload": NORTH_STAR_WORKLOAD, "frac": target["frac"],
+                                            "frac_cold": target.get("frac_cold"),
                                             "kernel_avg_ms": target["kernel_avg_ms"],
+                                            "kernel_avg_ms_cold": target.get("kernel_avg_ms_cold"),
                                             "value": target["value"], "unit": "GB/s"}
             if not a.no_big:
                 try:
@@ -617,12 +819,13 @@ def main():
                     torch.cuda.empty_cache()
             if not a.no_end_to_end and not is_async:
                 out["end_to_end"] = end_to_end(wl)
+                out["end_to_end_wire"] = end_to_end_wire(wl)
                 if name != NORTH_STAR_WORKLOAD:
                     # the same PCIe-inclusive measurement on the north-star target configuration
                     e2e = end_to_end(W.WORKLOADS[NORTH_STAR_WORKLOAD], rounds=3, arrivals=3)
                     e2e["workload"] = NORTH_STAR_WORKLOAD
                     out["end_to_end_north_star"] = e2e
-        if not a.no_cpu_baseline and bench_class(wl) is not AdmmBench:
+        if not a.no_cpu_baseline and bench_class(wl) not in (AdmmBench, MixBench):
             naive, fused = cpu_baseline(wl, a.cpu_seconds)
             out["cpu_baseline"] = naive
             out["cpu_baseline_fused"] = fused

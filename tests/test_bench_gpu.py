@@ -34,6 +34,8 @@ def test_one_rank_nccl_run_reports_the_three_sharded_forms():
     assert r.returncode == 0, r.stderr[-3000:]
     out = _json_line(r.stdout)
     assert out["scaling"] == "strong" and out["n_gpus"] == 1
+    # the process group's own size and every rank's device identity (host | uuid | PCI address)
+    assert out["ranks"] == 1 and len(out["devices"]) == 1 and out["devices"][0].count("|") == 2
     for form in ("no_collective", "allgather", "allgather_pipelined"):
         assert out[form]["value"] > 0 and out[form]["ms_per_step"] > 0
     assert out["value"] == out["allgather_pipelined"]["value"]
@@ -57,11 +59,24 @@ def test_one_gpu_line_lists_every_benchmark_configuration():
     out = _json_line(r.stdout)
     assert out["config"]["workload"] == "resnet18_fedavg_k100" and out["scaling"] == "weak"
     names = [w["workload"] for w in out["workloads"]]
-    assert names == ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "flat162m_fedavg_k32",
-                     "vitb16_fedasync", "vitb16_fedbuff_k16", "resnet50_iiadmm_k16", "resnet50_iceadmm_k16"]
+    assert names == ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "resnet50_fedavgm_k64",
+                     "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
+                     "vitb16_fedbuff_first", "vitb16_fedbuff_middle", "vitb16_fedbuff_flush",
+                     "vitb16_fedcompass_group_k8", "vitb16_fedqueue_replace_k16"]
+    by_name = {w["workload"]: w for w in out["workloads"]}
     for w in out["workloads"]:
         assert 0 < w["frac"] < 1
         assert abs(w["frac"] - w["algorithmic_bytes_per_launch"] / (w["kernel_avg_ms"] * 1e-3) / 8e12) < 2e-3
+    n_vit = by_name["vitb16_fedbuff_k16"]["algorithmic_bytes_per_launch"] // 16
+    assert [by_name["vitb16_fedbuff_" + k]["algorithmic_bytes_per_launch"] // n_vit
+            for k in ("first", "middle", "flush")] == [12, 16, 20]
+    assert by_name["vitb16_fedcompass_group_k8"]["algorithmic_bytes_per_launch"] == 4 * (8 + 2) * n_vit
+    assert by_name["vitb16_fedqueue_replace_k16"]["algorithmic_bytes_per_launch"] == 4 * (16 + 1) * n_vit
     assert out["north_star_target"]["workload"] == "resnet50_fedadam_k64"
     assert out["north_star_target"]["frac"] == out["workloads"][0]["frac"]
+    # cold-state figures (state vectors rotated over independent sets) beside the warm ones
+    assert out["ranks"] == 1 and len(out["devices"]) == 1
+    for rec in (out["roofline"], by_name["resnet50_fedadam_k64"], by_name["flat162m_fedavg_k32"]):
+        assert 0 < rec["frac_cold"] < 1 and rec["state_sets"] >= 3
+    assert out["north_star_target"]["frac_cold"] == by_name["resnet50_fedadam_k64"]["frac_cold"]
     assert out["roofline"]["traffic"] is None or out["roofline"]["traffic_source"]
