@@ -17,9 +17,10 @@ from typing import Any, Dict, Union
 
 
 class SerialSyncHarness:
-    def __init__(self, aggregator: Any, num_clients: int):
+    def __init__(self, aggregator: Any, num_clients: int, stage_on_arrival: bool = True):
         self.aggregator = aggregator
         self.num_clients = num_clients
+        self.stage_on_arrival = stage_on_arrival     # False: store only, as the reference's scheduler does
         self.local_models: Dict[Union[int, str], Dict] = {}
         self.aggregation_kwargs: Dict[str, Dict] = {}
         self.future: Dict[Union[int, str], Future] = {}
@@ -59,7 +60,7 @@ class SerialSyncHarness:
             # scheduler-side staging: start this client's upload while the others are awaited
             # (a chunk of a streamed round is aggregated per chunk, not staged as a whole update)
             stage = getattr(self.aggregator, "stage", None)
-            if callable(stage) and "_chunk_idx" not in kwargs:
+            if self.stage_on_arrival and callable(stage) and "_chunk_idx" not in kwargs:
                 stage(client_id, local_model)
             for key, value in kwargs.items():
                 self.aggregation_kwargs.setdefault(key, {})[client_id] = value

@@ -592,3 +592,54 @@ def test_fedbuff_early_download_matches_plain_path():
             assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape
             assert golden_util.same_bits(got[k].numpy(), want[k].numpy()), (i, k)
             assert golden_util.same_bits(got[k].numpy(), ref[k]), (i, k)
+
+
+def test_staging_scheduler_subclass_drives_the_device_aggregator():
+    """`plugin.staging_scheduler_class` over a scheduler that only stores (as the reference's
+    SyncScheduler does): every arrival is uploaded when it is scheduled -- also one handed over as
+    `torch.save` bytes -- and the rounds give the bits of the same rounds without any staging."""
+    import io
+
+    import appfl_amd.aggregator as A
+    from appfl_amd import harness as H, plugin
+
+    class StoreOnly:
+        def __init__(self, cfg, aggregator, logger):
+            self.aggregator = aggregator
+            self.h = H.SerialSyncHarness(aggregator, cfg["num_clients"], stage_on_arrival=False)
+
+        def schedule(self, client_id, local_model, **kwargs):
+            return self.h.global_update(client_id, local_model, **kwargs)
+
+    K = 4
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size", num_clients=K)
+    plain, staged = A.FedAdamAggregator(S.ToyModel(), cfg, None), A.FedAdamAggregator(S.ToyModel(), cfg, None)
+    for agg in (plain, staged):
+        for c in range(K):
+            agg.set_client_sample_size(c, 3 + 2 * c)
+    uploads = []
+    real_stage = staged.stage
+
+    def spy(client_id, model):
+        uploads.append(client_id)
+        return real_stage(client_id, model)
+    staged.stage = spy
+    scheds = [StoreOnly({"num_clients": K}, plain, None),
+              plugin.staging_scheduler_class(StoreOnly)({"num_clients": K}, staged, None)]
+    for r in range(3):
+        models = {c: S.make_state(S.TOY, seed=500 + 10 * r + c) for c in range(K)}
+        outs = []
+        for i, sched in enumerate(scheds):
+            futs = []
+            for c, m in models.items():
+                payload = {k: v.clone() for k, v in m.items()}
+                if i == 1 and c == 2:                      # this one arrives in wire form
+                    buf = io.BytesIO()
+                    torch.save(payload, buf)
+                    payload = buf.getvalue()
+                futs.append(sched.schedule(c, payload, round=r))
+            assert all(f.done() for f in futs) and all(f.result() is futs[0].result() for f in futs)
+            outs.append(futs[0].result())
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), (r, k)
+    assert uploads == list(range(K)) * 3

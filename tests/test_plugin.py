@@ -112,3 +112,124 @@ def test_register_against_the_reference_aggregator_module():
     r = subprocess.run([sys.executable, "-c", _REAL_MODULE_CHECK.format(root=root)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
+def test_staging_scheduler_class_on_a_fake_stock_scheduler():
+    """No reference needed: `stage` once per arrival, before the stock method stores the model;
+    chunks of a streamed round, flat secure-aggregation payloads and aggregators without a
+    `stage` method pass straight through; bytes go to `stage_bytes` and its views travel on."""
+    calls = []
+
+    class Stock:
+        def __init__(self, cfg, aggregator, logger):
+            self.aggregator, self.stored = aggregator, []
+
+        def schedule(self, client_id, local_model, **kwargs):
+            calls.append(("store", client_id))
+            self.stored.append((client_id, local_model, kwargs))
+            return "future"
+
+    class Agg:
+        def stage(self, client_id, model):
+            calls.append(("stage", client_id))
+
+        def stage_bytes(self, client_id, b):
+            calls.append(("stage_bytes", client_id))
+            return {"w": len(b)}
+
+    cls = plugin.staging_scheduler_class(Stock, "XSync")
+    assert cls.__name__ == "XSync" and issubclass(cls, Stock)
+    sched = cls({}, Agg(), None)
+    assert sched.schedule("a", {"w": 1}, round=3) == "future"
+    assert sched.schedule("b", b"12345") == "future"
+    sched.schedule("c", {"w": 2}, _chunk_idx=0, _total_chunks=2, _chunk_keys=["w"])
+    sched.schedule("d", {"type": "masked_update_flat", "flat": None})
+    assert calls == [("stage", "a"), ("store", "a"), ("stage_bytes", "b"), ("store", "b"),
+                     ("store", "c"), ("store", "d")]
+    assert sched.stored[0][2] == {"round": 3} and sched.stored[1][1] == {"w": 5}
+    plain = cls({}, object(), None)                       # an aggregator without the hook
+    del calls[:]
+    plain.schedule("e", {"w": 1})
+    assert calls == [("store", "e")]
+
+
+_REAL_SCHEDULER_CHECK = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests"); sys.path.insert(0, {root!r} + "/tests/golden")
+import gen_golden
+gen_golden.import_reference()
+import importlib
+from concurrent.futures import Future
+import golden_util
+import scenarios as S
+from oracle import aggregators as OA
+from appfl_amd import plugin
+sched_mod = importlib.import_module("appfl.algorithm.scheduler")
+stock = sched_mod.SyncScheduler
+reg = plugin.register(replace=True, stage_on_arrival=True)
+from appfl.misc.utils import get_appfl_scheduler
+cls = sched_mod.SyncScheduler
+assert cls is reg["SyncScheduler"] is sched_mod.MI355XSyncScheduler and sched_mod.StockSyncScheduler is stock
+assert issubclass(cls, stock) and cls.schedule is not stock.schedule
+for meth in ("get_parameters", "get_num_global_epochs", "set_num_clients", "_parse_aggregated_model"):
+    assert getattr(cls, meth) is getattr(stock, meth), meth          # everything else is the stock code
+
+staged, rounds = [], []
+
+def spying(base):
+    class Spy(base):
+        def stage(self, client_id, model):
+            staged.append((client_id, model))
+        def aggregate(self, local_models, **kwargs):
+            rounds.append((dict(local_models), "_chunk_idx" in kwargs))
+            return super().aggregate(local_models, **kwargs)
+    return Spy
+
+def factory(name, model, cfg):
+    return spying(OA.ORACLES[name])(model, cfg, None)
+
+def schedulers(kind, agg, num_clients=0):
+    assert kind == "sync"
+    # the loader the server agent uses (misc/utils.py:147-159) resolves the stock NAME
+    return get_appfl_scheduler("SyncScheduler", gen_golden.DictConfig({{"num_clients": num_clients,
+                               "same_init_model": True}}), agg, None)
+
+ran = 0
+for sc in S.all_scenarios():
+    if sc["kind"] != "sched_sync":
+        continue
+    del staged[:], rounds[:]
+    rec = S.run_scenario(factory, sc, schedulers)
+    golden_util.check_records(sc["id"], rec, S.reference_rtol(sc))    # Futures, shared result, epochs, values
+    whole = [(models, chunk) for models, chunk in rounds if not chunk]
+    arrivals = sum(len(models) for models, _ in whole)
+    assert len(staged) == arrivals > 0, (sc["id"], len(staged), arrivals)
+    it = iter(staged)
+    for models, _ in whole:              # staged in arrival order, the very objects aggregate() receives
+        for cid, model in models.items():
+            s_cid, s_model = next(it)
+            assert s_cid == cid and s_model is model, (sc["id"], cid)
+    ran += 1
+assert ran >= 2, ran
+print("ok", ran)
+"""
+
+
+def test_staging_scheduler_behind_the_reference_sync_scheduler():
+    """Container-only: `register(stage_on_arrival=True)` against the reference's REAL
+    `SyncScheduler`, resolved through the reference's own loader; the scheduler-driven golden
+    scenarios (Futures and their `done()` pattern, one shared result object, epoch counts, a
+    streamed round) are reproduced with the staging subclass in place, and `stage` saw every
+    arrival of every whole-model round exactly once, in order, with the object `aggregate`
+    later received."""
+    import os
+    import subprocess
+    import sys
+
+    import pytest
+    if not os.path.isdir("/root/reference/src/appfl"):
+        pytest.skip("the reference checkout is not present on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _REAL_SCHEDULER_CHECK.format(root=root)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), r.stderr[-3000:]
