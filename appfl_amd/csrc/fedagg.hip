@@ -298,7 +298,10 @@ __device__ __forceinline__ void fold_batch(const ReduceArgs& a, int k, const uns
 // Folds the K clients of this launch into the step of the vectors idx[0..VPT) and, on the last
 // client chunk, runs the optimizer epilogue and forms g + step.  Everything stays in registers;
 // the caller decides how the results reach memory.
-template <int OPT, int VEC, int VPT, int U, bool NT>
+// STEP_ONLY: stop after the clients (the averaged step in r.s, g as read in r.g) whatever a.last
+// says -- for callers that run the epilogue themselves, later; g is then read with the caching
+// policy, because the caller reads it again soon.
+template <int OPT, int VEC, int VPT, int U, bool NT, bool STEP_ONLY = false>
 __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&idx)[VPT],
                                           TileRegs<VEC, VPT>& r) {
     const float* gsrc = a.apply ? a.g : a.g_ro;
@@ -307,7 +310,7 @@ __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&
         // g, m and v are read once per round like the client rows, but whether the streaming
         // (nt) policy pays differs: measured +2 % for g under plain FedAvg, -1.5 % for g beside
         // two moment streams, +1.5-7 % for m / v of the two-moment optimizers, -1 % for FedAvgM's v.
-        r.g[p] = (OPT == FA_OPT_NONE) ? load_stream<VEC, true>(gsrc, idx[p]) : load_state<VEC>(gsrc, idx[p]);
+        r.g[p] = (OPT == FA_OPT_NONE && !STEP_ONLY) ? load_stream<VEC, true>(gsrc, idx[p]) : load_state<VEC>(gsrc, idx[p]);
         if (a.step_in) {
             r.s[p] = load_state<VEC>(a.step_in, idx[p]);
         } else {
@@ -328,7 +331,7 @@ __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&
     }
     if (k + 2 <= a.K) { fold_batch<VEC, VPT, 2, NT>(a, k, idx, r); k += 2; }
     if (k < a.K) fold_batch<VEC, VPT, 1, NT>(a, k, idx, r);
-    if (!a.last) return;
+    if (STEP_ONLY || !a.last) return;
 #pragma unroll
     for (int p = 0; p < VPT; ++p) {
         if (OPT != FA_OPT_NONE) {
@@ -937,6 +940,161 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent kernel with a LATE optimizer epilogue, for FedAvgM / FedAdam / FedYogi / FedAdagrad.
+// The fused kernels above write g, m and v of every tile as soon as its clients are folded: three
+// (two) thin result streams trickling out among the reads, which is what holds the two-moment
+// optimizers at 0.69-0.72 of peak at 16-40 clients, and with three result vectors per tile LDS
+// can only park 3 tiles per phase.  Here a tile's clients are folded the way the wide shape does
+// (16 clients x 4 vectors in flight per lane) into the AVERAGED STEP alone, which is parked in LDS
+// -- one vector per tile, so TEN tiles per phase like plain FedAvg's wide-batch kernel -- and the
+// epilogue runs at the end of the phase over the ten parked tiles: g, m and v are read (g for the
+// second time, a few hundred microseconds after the first: 4 of 4 (K + 6) + 4 bytes per
+// parameter), the optimizer formulas evaluated, g, m and v written.  A phase is therefore a long
+// stretch of pure reads followed by a copy-like burst (as many bytes read as written, each CU on
+// its own ten tiles), the two mixes HBM serves best, in the same chip-wide staggered phases.
+// Same operations on the same values in the same order as the fused kernels: same bits.
+#ifndef FA_LATE_BATCH
+#define FA_LATE_BATCH 3
+#endif
+constexpr int kLateBatch = FA_LATE_BATCH;   // tiles whose g / m / v the epilogue requests at once
+constexpr unsigned kLatePhaseTiles = 6;
+
+template <int OPT>
+__global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceArgs a) {
+    static_assert(OPT != FA_OPT_NONE, "plain FedAvg has no epilogue to defer");
+    constexpr int S = (kStashBytes / kStashVecBytes) > kStashMaxTiles ? kStashMaxTiles : (kStashBytes / kStashVecBytes);
+    constexpr int VPT = kStashVpt;
+    constexpr bool kHasM = OPT >= FA_OPT_ADAM;
+    __shared__ f4 stash[S][VPT][kThreads];
+    const unsigned per_round = gridDim.x * kStashTile;
+    const unsigned rounds = (a.n + per_round - 1) / per_round;
+    const unsigned slots = gridDim.x * rounds;
+    const unsigned tlen = (((a.n + slots - 1) / slots) + 63u) & ~63u;
+    const unsigned total = (a.n + tlen - 1) / tlen;
+    unsigned slot = blockIdx.x;
+    if (gridDim.x % 8 == 0) slot = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    if (a.mt.total) mean_tail(a, gridDim.x - 1u - slot);
+    const unsigned most = (total + gridDim.x - 1) / gridDim.x;
+    // phases of six tiles (kernel time against ten, all that LDS holds: -1.5...-2 % at 25 M elements
+    // x 24-32 clients, -1 % on 87-162 M x 32)
+    unsigned P = kLatePhaseTiles;
+    bool phased = a.sync != 0 && a.sync_word != nullptr;
+    if (a.phase_tiles > 0) P = static_cast<unsigned>(a.phase_tiles) < static_cast<unsigned>(S) ? static_cast<unsigned>(a.phase_tiles) : static_cast<unsigned>(S);
+    if (most <= P) phased = false;
+    GridMeet meet = {a.sync_word, 0u, false, gridDim.x};
+    unsigned shift = 0, meetings = 0;
+    if (phased && (a.sync >> 2) && gridDim.x % 8 == 0) {
+        const unsigned mode = static_cast<unsigned>(a.sync >> 2) & 3u;
+        const unsigned xcd = blockIdx.x % 8u;
+        const unsigned groups = mode == 2u ? 4u : 2u;
+        const unsigned group = mode == 3u ? xcd >> 2 : xcd % groups;
+        meet.word = a.sync_word + 4u * group;
+        meet.blocks = gridDim.x / groups;
+        shift = group * P / groups;
+    }
+    if (phased) meetings = (most + shift + P - 1) / P;
+    if (phased) grid_meet_enter(meet, a.sync_epoch);
+    if (slot >= total) {
+        if (phased) grid_meet_leave(meet, meetings);
+        return;
+    }
+    const unsigned ntiles = (total - slot + gridDim.x - 1) / gridDim.x;
+    const unsigned r0 = slot * tlen, r1 = a.n, tstride = gridDim.x * tlen;
+    const unsigned nbytes = a.n * 16u;
+    auto tile_index = [&](unsigned tile, int p, bool& live) -> unsigned {
+        const unsigned off = p * kThreads + threadIdx.x;
+        const unsigned i = r0 + tile * tstride + off;
+        live = off < tlen && i < r1;
+        return live ? i : r1 - 1;   // idle lanes redo the last vector, never store
+    };
+    auto as_f4 = [](const Pack<4>& v) {
+        f4 t;
+        t.x = v.e[0]; t.y = v.e[1]; t.z = v.e[2]; t.w = v.e[3];
+        return t;
+    };
+    for (unsigned ct = 0; ct < ntiles; ++ct) {
+        unsigned idx[VPT];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            bool live;
+            idx[p] = tile_index(ct, p, live);
+        }
+        TileRegs<4, VPT> r;
+        fold_tile<FA_OPT_NONE, 4, VPT, 16, true, true>(a, idx, r);
+        const int j = static_cast<int>((ct + shift) % P);
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) stash[j][p][threadIdx.x] = as_f4(r.s[p]);
+        if (j == static_cast<int>(P) - 1 || ct + 1 == ntiles) {
+            const unsigned first = ct - static_cast<unsigned>(j);
+            const int j_lo = (ct < P && static_cast<unsigned>(j) >= ct) ? j - static_cast<int>(ct) : 0;
+            if (phased) grid_meet(meet);
+            // The epilogue over the parked tiles, kLateBatch tiles at a time: all of a batch's
+            // g / m / v loads are issued at once (3 x 4 x kLateBatch 16-byte loads in flight per
+            // lane, so the burst streams like the client reads do), and the next batch's loads
+            // fly while this batch's formulas are evaluated and its results stored.
+            constexpr int B = kLateBatch;
+            Pack<4> gq[2][B][VPT], mq[2][B][VPT], vq[2][B][VPT];
+            auto fetch = [&](int jj0, auto bsel) {
+                constexpr int b = decltype(bsel)::value;
+#pragma unroll
+                for (int t = 0; t < B; ++t) {
+                    const int jj = jj0 + t <= j ? jj0 + t : j;   // past the end: redo the last tile's loads
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        bool live;
+                        const unsigned i = tile_index(first + jj, p, live);
+                        gq[b][t][p] = load_state<4>(a.g, i);
+                        vq[b][t][p] = kHasM ? load_stream<4, true>(a.v, i) : load_state<4>(a.v, i);
+                        if (kHasM) mq[b][t][p] = load_stream<4, true>(a.m, i);
+                    }
+                }
+            };
+            auto finish = [&](int jj0, auto bsel) {
+                constexpr int b = decltype(bsel)::value;
+#pragma unroll
+                for (int t = 0; t < B; ++t) {
+                    const int jj = jj0 + t;
+                    if (jj > j) break;
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        bool live;
+                        const unsigned i = tile_index(first + jj, p, live);
+                        const f4 st = stash[jj][p][threadIdx.x];
+                        float sv[4] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float mj = kHasM ? mq[b][t][p].e[e] : 0.0f;
+                            const float step = optimizer_step<OPT>(sv[e], mj, vq[b][t][p].e[e], a.h);
+                            if (kHasM) mq[b][t][p].e[e] = mj;
+                            gq[b][t][p].e[e] = gq[b][t][p].e[e] + step;
+                        }
+                        if (live) {
+                            burst_store(a.g, nbytes, i, as_f4(gq[b][t][p]));
+                            burst_store(a.v, nbytes, i, as_f4(vq[b][t][p]));
+                            if (kHasM) burst_store(a.m, nbytes, i, as_f4(mq[b][t][p]));
+                        }
+                    }
+                }
+            };
+            using B0 = std::integral_constant<int, 0>;
+            using B1 = std::integral_constant<int, 1>;
+            fetch(j_lo, B0{});
+#pragma unroll 1
+            for (int jj = j_lo; jj <= j; jj += 2 * B) {
+                if (jj + B <= j) fetch(jj + B, B1{});
+                finish(jj, B0{});
+                if (jj + B <= j) {
+                    if (jj + 2 * B <= j) fetch(jj + 2 * B, B0{});
+                    finish(jj + B, B1{});
+                }
+            }
+            if (phased) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain before the next phase's loads
+        }
+    }
+    if (phased) grid_meet_leave(meet, meetings);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Plain mean over clients (entries that bypass the weighted step).
 
 template <typename T>
@@ -1389,6 +1547,45 @@ int launch_park(const ReduceArgs& a0, hipStream_t st) {
     return launch_status();
 }
 
+template <int OPT>
+int launch_late(const ReduceArgs& a0, hipStream_t st) {
+    if constexpr (OPT == FA_OPT_NONE) {
+        return FA_ERR_INVALID;
+    } else {
+        ReduceArgs a = a0;
+        a.sync_word = a.sync ? next_sync_word(st, &a.sync_epoch) : nullptr;
+        hipLaunchKernelGGL((reduce_late_kernel<OPT>), dim3(device_cu_count()), dim3(kThreads), 0, st, a);
+        return launch_status();
+    }
+}
+
+// Whether a launch takes the persistent kernel with the late epilogue: the final form (weighted
+// step, epilogue, apply; no step output) of the TWO-MOMENT optimizers at mid-size client lists,
+// where neither the tile-per-block kernel hides the three result streams nor the software-pipelined
+// persistent kernel's two-tile phases pay yet (stash_wins below has priority).  Measured against
+// the tile-per-block kernel, same process (kernel time): 25.6 M elements x 24 / 28 / 32 / 36 clients
+// -1.2...-1.9 / -3.3 / -4.2...-4.9 / -3.5 %, 18 M x 32 -4.2 %, 35 M x 20 / 24 / 28 -3.7 / -3.6 / -3.0 %,
+// 47 M x 20 -2.1 %, 60 M x 16 / 20 -1.5 / -3.1 %; level or behind at 11.7 M elements (+-1 %, +3 % at
+// 24 clients), at 25.6 M x 16-20 (+1.4...+3 %) and wherever the pipelined persistent kernel is the
+// default (35 M x 32 +1 %, 87-162 M x 32 +3...+6 %, 25.6 M x 48-64 +-1 %); FedAvgM loses 7 % (its
+// wide tile-per-block shape is at 0.78 already).  fa_tune: stash == -3 forces it at every length
+// and client count, stash <= 0 otherwise keeps it off.
+bool late_wins(int opt, int K, uint64_t tiles_per_cu) {
+    if (opt < FA_OPT_ADAM) return false;
+    return (K >= 24 && tiles_per_cu >= 16) || (K >= 20 && tiles_per_cu >= 32) || (K >= 16 && tiles_per_cu >= 56);
+}
+bool stash_wins(int opt, int K, uint64_t tiles_per_cu);
+bool takes_late_path(int opt, int K, uint64_t nvec) {
+    if (opt == FA_OPT_NONE || K > FA_KCHUNK) return false;
+    if (g_call_flags & FA_ROUTE_NO_PERSISTENT) return false;
+    if (g_shape.stash == -3) return true;
+    if (g_shape.stash <= 0) return false;
+    const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
+    const uint64_t tiles_per_cu = nvec / per_cu;
+    if (nvec >= per_cu * static_cast<uint64_t>(g_shape.stash) && stash_wins(opt, K, tiles_per_cu)) return false;
+    return late_wins(opt, K, tiles_per_cu);
+}
+
 // Whether a launch takes the wide-batch persistent kernel: plain FedAvg, final form, from 6
 // clients on vectors of at least kParkMinTilesPerCu tiles per CU (fa_tune: stash == -2 forces it
 // at every length and client count, stash == 0 / -1 keep it off).  Against the tile-per-block
@@ -1473,6 +1670,8 @@ int launch_reduce_t(const ReduceArgs& a, hipStream_t st) {
             takes_park_path(FA_OPT_NONE, a.K, a.n, true))
             return launch_park<FA_OPT_NONE>(a, st);
     }
+    if (OPT != FA_OPT_NONE && a.last && a.apply && !a.step_out && takes_late_path(OPT, a.K, a.n))
+        return launch_late<OPT>(a, st);
     if (takes_stash_path(OPT, a.K, a.n)) return launch_stash<OPT>(a, st);
     int vpt = g_shape.vpt, unroll = g_shape.unroll;
     if (vpt == 0) {
@@ -1911,6 +2110,7 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt) {
     const int k = K > FA_KCHUNK ? FA_KCHUNK : K;
     const uint64_t seg = n > kSegment ? kSegment : n;
     if (takes_park_path(opt, k, seg / 4, K <= FA_KCHUNK)) return "reduce_park_kernel";
+    if (K <= FA_KCHUNK && takes_late_path(opt, k, seg / 4)) return "reduce_late_kernel";
     return takes_stash_path(opt, k, seg / 4) ? "reduce_stash_kernel" : "reduce_kernel";
 }
 

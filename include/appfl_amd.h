@@ -84,7 +84,12 @@ const char* fa_reduce_kernel_name(int K, size_t n, int opt);
  * more than 8 clients, default 2).  Plain FedAvg from 6 clients on vectors of >= 72 tiles per
  * CU takes the persistent kernel's wide-batch form (16 clients x 4 vectors in flight per lane,
  * phases of ten tiles); stash == -2 forces that form at every length and client count, stash ==
- * -1 and 0 keep it off.  Results do not depend on any of this.
+ * -1 and 0 keep it off.  The two-moment optimizers at mid-size client lists (>= 24 clients on
+ * vectors of >= 16 tiles per CU, >= 20 on >= 32 tiles, >= 16 on >= 56 tiles, below the client
+ * counts above) take a persistent kernel that parks the averaged step alone and runs the
+ * optimizer epilogue at the end of each phase of six tiles; stash == -3 forces that kernel for
+ * every optimizer, length and client count, stash <= 0 otherwise keeps it off.  Results do not
+ * depend on any of this.
  * Applies to launches made by the calling thread only (thread-local state).
  */
 int fa_tune(int vpt, int unroll, int nt, int max_blocks, int stash);

@@ -830,3 +830,113 @@ def test_meeting_counters_heal_and_later_rounds_keep_their_speed():
         ops.reduce_opt(rows, w, g1)
     torch.cuda.synchronize()
     assert torch.equal(g1, ref)
+
+
+_CODES = {"avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI, "adagrad": O.OPT_ADAGRAD}
+
+
+@pytest.mark.parametrize("opt,hp", [("avgm", HP), ("adam", HP), ("yogi", HP_YOGI), ("adagrad", HP)])
+@pytest.mark.parametrize("n", [7, 1027, 300007, 4500003, 12000004])
+@pytest.mark.parametrize("K", [1, 6, 17, 49])
+@pytest.mark.parametrize("nt", [1, 65, 1025, 2561], ids=["default", "one_group", "phases_of_4", "phases_of_10"])
+def test_late_epilogue_persistent_kernel_matches_oracle(opt, hp, n, K, nt):
+    """The persistent kernel that parks the averaged step and runs the optimizer epilogue at the
+    end of a phase, forced on at every length -- no tile, partial tiles, more tiles per CU than
+    a phase parks -- and with other phase groupings and lengths: the oracle's bits for g, m and v,
+    two rounds in a row (the moments feed back)."""
+    from appfl_amd import ops
+    if n > 10_000_000 and K > 17:
+        pytest.skip("host memory")
+    base, xs = make_clients(n, K)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref, m_ref = base.copy(), np.zeros_like(base)
+    v_ref = np.full_like(base, np.float32(0.0 if opt == "avgm" else hp["tau"] ** 2))
+    g, m, v = dev(base), dev(m_ref.copy()), dev(v_ref.copy())
+    dx = [dev(x) for x in xs]
+    try:
+        ops.tune(nt=nt, stash=-3)
+        assert ops.reduce_kernel_name(K, n, opt) == "reduce_late_kernel"
+        for rnd in range(2):
+            O.reduce_opt(xs, w, g_ref, m_ref, v_ref, _CODES[opt], **hp)
+            ops.reduce_opt(dx, w, g, m if opt != "avgm" else None, v, opt, **hp)
+            assert_bits(g, g_ref, f"g round {rnd}")
+            assert_bits(v, v_ref, f"v round {rnd}")
+            if opt != "avgm":
+                assert_bits(m, m_ref, f"m round {rnd}")
+    finally:
+        ops.tune()
+
+
+def test_late_epilogue_kernel_where_the_library_routes_to_it():
+    """Mid-size client lists of the two-moment optimizers on vectors of >= 16 tiles per CU take
+    the late-epilogue kernel by default (several phases per group, a scalar tail after the 128-bit
+    body); shorter client lists, shorter vectors, FedAvgM and the shapes of the pipelined
+    persistent kernel do not.  The oracle's bits, moments included, three rounds."""
+    from appfl_amd import ops
+    name = ops.reduce_kernel_name
+    assert name(32, 25_557_032, "adam") == name(24, 18_000_000, "yogi") == "reduce_late_kernel"
+    assert name(20, 35_000_000, "adagrad") == name(16, 60_000_000, "adam") == "reduce_late_kernel"
+    assert name(20, 25_557_032, "adam") == name(32, 11_689_512, "adam") == "reduce_kernel"
+    assert name(32, 25_557_032, "avgm") == "reduce_kernel" and name(32, 25_557_032, "none") == "reduce_kernel"
+    assert name(64, 25_557_032, "adam") == name(32, 35_000_000, "adam") == "reduce_stash_kernel"
+    n, K = 17_000_003, 24
+    base, xs = make_clients(n, K, spike=False)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref, m_ref, v_ref = base.copy(), np.zeros_like(base), np.full_like(base, np.float32(1e-6))
+    g, m, v = dev(base), dev(m_ref.copy()), dev(v_ref.copy())
+    dx = [dev(x) for x in xs]
+    assert name(K, n, "yogi") == "reduce_late_kernel"
+    for rnd in range(3):
+        O.reduce_opt(xs, w, g_ref, m_ref, v_ref, O.OPT_YOGI, **HP_YOGI)
+        ops.reduce_opt(dx, w, g, m, v, "yogi", **HP_YOGI)
+        assert_bits(g, g_ref, f"g round {rnd}")
+        assert_bits(m, m_ref, f"m round {rnd}")
+        assert_bits(v, v_ref, f"v round {rnd}")
+
+
+def test_late_epilogue_kernel_after_client_chunks_and_beside_other_work():
+    """K > FA_KCHUNK: the last chunk's launch starts from the carried step and runs the late
+    epilogue.  With another stream's kernels holding CUs the phased launch still ends with the
+    oracle's bits."""
+    from appfl_amd import ops
+    n, K = 6_000_004, ops.kchunk() + 16
+    base, xs24 = make_clients(n, 24, spike=False)
+    xs = [xs24[k % 24] for k in range(K)]
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref, m_ref, v_ref = base.copy(), np.zeros_like(base), np.full_like(base, np.float32(1e-6))
+    dx24 = [dev(x) for x in xs24]
+    dx = [dx24[k % 24] for k in range(K)]
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    b = torch.empty_like(a)
+    g, m, v = dev(base), dev(m_ref.copy()), dev(v_ref.copy())
+    ws = torch.empty_like(g)
+    try:
+        ops.tune(stash=-3)
+        for rnd in range(2):
+            O.reduce_opt(xs, w, g_ref, m_ref, v_ref, O.OPT_ADAM, **HP)
+            with torch.cuda.stream(side):
+                for _ in range(30):
+                    torch.mm(a, a, out=b)
+            ops.reduce_opt(dx, w, g, m, v, "adam", step_ws=ws, **HP)
+            torch.cuda.synchronize()
+            assert_bits(g, g_ref, f"g round {rnd}")
+            assert_bits(m, m_ref, f"m round {rnd}")
+            assert_bits(v, v_ref, f"v round {rnd}")
+    finally:
+        ops.tune()
+
+
+@pytest.mark.parametrize("n_step,K,counts", [
+    (300007, 17, (300, 20, 9)), (2500003, 40, (0, 20, 0)), (2500003, 100, (9000, 53, 5)),
+    (11000003, 16, (0, 20, 0)),
+])
+def test_round_on_the_late_epilogue_kernel(n_step, K, counts):
+    """fa_round with the late-epilogue kernel forced on: the plain means ride in its launch."""
+    from appfl_amd import ops
+    try:
+        ops.tune(stash=-3)
+        assert ops.reduce_kernel_name(K, n_step, "adam") == "reduce_late_kernel"
+        _check_round("adam", HP, n_step, K, counts)
+    finally:
+        ops.tune()
