@@ -1147,11 +1147,18 @@ struct MixArgs {
     float coeff;
 };
 
-template <int VEC, int VPT, int U>
+// The combine mode is a template parameter (no run-time branches in the client loop).
+template <int VEC, int VPT, int U, int MODE>
 __global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
     constexpr unsigned kTile = kThreads * VPT;
     const unsigned tiles = (a.n + kTile - 1) / kTile;
-    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+    // the reduce kernel's XCD-contiguous tile order: inside windows of 8 * R tiles each XCD takes R
+    // consecutive tiles instead of every eighth one
+    constexpr unsigned R = 128u;
+    for (unsigned t0 = blockIdx.x; t0 < tiles; t0 += gridDim.x) {
+        unsigned t = t0;
+        const unsigned win = t0 & ~(8u * R - 1u);
+        if (VEC == 4 && win + 8u * R <= tiles) t = win + (t0 & 7u) * R + ((t0 >> 3) & (R - 1u));
         unsigned idx[VPT];
         bool ok[VPT];
 #pragma unroll
@@ -1163,14 +1170,14 @@ __global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
         Pack<VEC> acc[VPT], g[VPT];
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
-            if (a.mode != FA_MIX_REPLACE && a.mode != FA_MIX_SUM_SET) g[p] = load_state<VEC>(a.g, idx[p]);
-            if (a.mode == FA_MIX_SUBTRACT) {
+            if (MODE != FA_MIX_REPLACE && MODE != FA_MIX_SUM_SET) g[p] = load_state<VEC>(a.g, idx[p]);
+            if (MODE == FA_MIX_SUBTRACT) {
                 acc[p] = g[p];
             } else if (a.acc_in) {
                 acc[p] = load_state<VEC>(a.acc_in, idx[p]);
             } else {
                 // -0 + y == y for every y, so the single-arrival form adds x*w to nothing
-                const float zero = (a.mode >= FA_MIX_CONVEX_ONE) ? -0.0f : 0.0f;
+                const float zero = (MODE >= FA_MIX_CONVEX_ONE) ? -0.0f : 0.0f;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[p].e[j] = zero;
             }
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 float xw = x.e[j] * wk;
-                acc[p].e[j] = (a.mode == FA_MIX_SUBTRACT) ? acc[p].e[j] - xw : acc[p].e[j] + xw;
+                acc[p].e[j] = (MODE == FA_MIX_SUBTRACT) ? acc[p].e[j] - xw : acc[p].e[j] + xw;
             }
         };
         // B clients: all their loads, then the arithmetic in client order
@@ -1209,18 +1216,18 @@ __global__ __launch_bounds__(kThreads) void mix_kernel(const MixArgs a) {
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
             if (!ok[p]) continue;
-            if (!a.last && a.mode != FA_MIX_SUBTRACT) {
+            if (!a.last && MODE != FA_MIX_SUBTRACT) {
                 store_result(a.acc_out, idx[p], acc[p], 1);
                 continue;
             }
-            if ((a.mode == FA_MIX_CONVEX || a.mode == FA_MIX_CONVEX_ONE) && a.last) {
+            if ((MODE == FA_MIX_CONVEX || MODE == FA_MIX_CONVEX_ONE) && a.last) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     float gt = g[p].e[j] * a.coeff;
                     acc[p].e[j] = gt + acc[p].e[j];
                 }
             }
-            if (a.mode == FA_MIX_SUM_ADD && a.last) {
+            if (MODE == FA_MIX_SUM_ADD && a.last) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) acc[p].e[j] = g[p].e[j] + acc[p].e[j];
             }
@@ -2097,6 +2104,47 @@ PackPool* pack_pool() {
 
 }  // namespace
 
+namespace {
+
+template <int VEC, int VPT, int U>
+int launch_mix_m(const MixArgs& a, unsigned grid, hipStream_t st) {
+    switch (a.mode) {
+        case FA_MIX_REPLACE: hipLaunchKernelGGL((mix_kernel<VEC, VPT, U, FA_MIX_REPLACE>), dim3(grid), dim3(kThreads), 0, st, a); break;
+        case FA_MIX_CONVEX: hipLaunchKernelGGL((mix_kernel<VEC, VPT, U, FA_MIX_CONVEX>), dim3(grid), dim3(kThreads), 0, st, a); break;
+        case FA_MIX_SUBTRACT: hipLaunchKernelGGL((mix_kernel<VEC, VPT, U, FA_MIX_SUBTRACT>), dim3(grid), dim3(kThreads), 0, st, a); break;
+        case FA_MIX_CONVEX_ONE: hipLaunchKernelGGL((mix_kernel<VEC, VPT, U, FA_MIX_CONVEX_ONE>), dim3(grid), dim3(kThreads), 0, st, a); break;
+        case FA_MIX_SUM_ADD: hipLaunchKernelGGL((mix_kernel<VEC, VPT, U, FA_MIX_SUM_ADD>), dim3(grid), dim3(kThreads), 0, st, a); break;
+        case FA_MIX_SUM_SET: hipLaunchKernelGGL((mix_kernel<VEC, VPT, U, FA_MIX_SUM_SET>), dim3(grid), dim3(kThreads), 0, st, a); break;
+        default: return FA_ERR_INVALID;
+    }
+    return launch_status();
+}
+
+// Launch shape of the mix kernel: 16 clients ahead, two vectors per thread from 8 clients on, one
+// below.  Measured (fraction of peak, replace / convex; 4 vectors x 8 ahead, the shape before ->
+// this rule): 86.6 M elements x 8 / 16 / 32 clients 0.74 / 0.72 / 0.73 -> 0.79 / 0.75 / 0.75, 25.6 M x
+// 8 / 16 / 32 / 64 0.78 / 0.76 / 0.77 / 0.78 -> 0.84 / 0.79 / 0.79 / 0.80, 4.5 M x 4 / 16 / 64 0.67 / 0.77 /
+// 0.78 -> 0.83 / 0.82 / 0.81.  The reduce kernel's wide shape (4 vectors x 16 ahead) does not carry
+// over: 0.57-0.59 from 16 clients on, with the combine mode compiled in or not.
+int launch_mix(const MixArgs& a, bool vec, hipStream_t st) {
+    if (!vec) return launch_mix_m<1, 1, 8>(a, grid_for(a.n), st);
+    auto grid = [&](unsigned vpt) {
+        const size_t tiles = (static_cast<size_t>(a.n) + kThreads * vpt - 1) / (kThreads * vpt);
+        return static_cast<unsigned>(tiles > static_cast<size_t>(kMaxBlocks) ? kMaxBlocks : (tiles < 1 ? 1 : tiles));
+    };
+    if (g_shape.vpt != 0) {   // fa_tune: a fixed shape (benchmark knob)
+        const int u = g_shape.unroll;
+        switch (g_shape.vpt) {
+            case 1: return u == 16 ? launch_mix_m<4, 1, 16>(a, grid(1), st) : launch_mix_m<4, 1, 8>(a, grid(1), st);
+            case 2: return u == 16 ? launch_mix_m<4, 2, 16>(a, grid(2), st) : launch_mix_m<4, 2, 8>(a, grid(2), st);
+            default: return u == 16 ? launch_mix_m<4, 4, 16>(a, grid(4), st) : launch_mix_m<4, 4, 8>(a, grid(4), st);
+        }
+    }
+    return a.K >= 8 ? launch_mix_m<4, 2, 16>(a, grid(2), st) : launch_mix_m<4, 1, 16>(a, grid(1), st);
+}
+
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 
@@ -2397,16 +2445,7 @@ int fa_weighted_mix(const float* const* x, const double* w, int K, float* g, dou
             a.mode = mode;
             a.last = (ch == chunks - 1);
             a.coeff = static_cast<float>(coeff);
-            if (vec) {
-                size_t tiles = (cnt + kThreads * 4 - 1) / (kThreads * 4);
-                // (16 clients ahead at one wave per SIMD, the reduce kernel's wide shape, runs this
-                // kernel at 0.48 of peak against 0.77: its combine modes are run-time branches)
-                hipLaunchKernelGGL((mix_kernel<4, 4, 8>), dim3(static_cast<unsigned>(tiles > size_t(kMaxBlocks) ? kMaxBlocks : tiles)),
-                                   dim3(kThreads), 0, st, a);
-            } else {
-                hipLaunchKernelGGL((mix_kernel<1, 1, 8>), dim3(grid_for(cnt)), dim3(kThreads), 0, st, a);
-            }
-            int rc = launch_status();
+            int rc = launch_mix(a, vec, st);
             if (rc != FA_OK) return rc;
         }
         return static_cast<int>(FA_OK);

@@ -118,6 +118,10 @@ WORKLOADS: Dict[str, Dict] = {
     "resnet18_fedavg_k100": {"table": lambda: resnet(18), "cls": "FedAvgAggregator", "K": 100},
     "resnet50_fedadam_k64": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 64},
     "resnet50_fedyogi_k64": {"table": lambda: resnet(50), "cls": "FedYogiAggregator", "K": 64},
+    # mid-size client lists of a two-moment optimizer (the persistent kernel with the late epilogue)
+    "resnet50_fedadam_k16": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 16},
+    "resnet50_fedadam_k24": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 24},
+    "resnet50_fedadam_k32": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 32},
     "resnet50_fedavg_k64": {"table": lambda: resnet(50), "cls": "FedAvgAggregator", "K": 64},
     "resnet50_fedavgm_k64": {"table": lambda: resnet(50), "cls": "FedAvgMAggregator", "K": 64},
     "vitb16_fedasync": {"table": vit_b_16, "cls": "FedAsyncAggregator", "K": 1},

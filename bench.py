@@ -74,6 +74,12 @@ def parse():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-big", action="store_true",
                     help="one GPU: skip the 166 GB strong-scaling reference run")
+    ap.add_argument("--cold", action="store_true",
+                    help="with --only: time the workload with its state vectors rotated over independent "
+                         "sets (cold state) instead of re-used ones -- for profiler runs of the cold figure")
+    ap.add_argument("--tune-stash", type=int, default=None,
+                    help="benchmark knob for A/B profiles: fa_tune's stash value (0: tile-per-block kernel "
+                         "only, -1 / -2 / -3: force one of the persistent kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="CPU time budget of each cpu_baseline leg")
     return ap.parse_args()
@@ -570,6 +576,40 @@ class ShardedBench:
         self.agg.round_sliced_gather(self.rows, self.weights, self.out)
 
 
+class WholeUpdateBench:
+    """The same round in the WHOLE-UPDATE mode: rank r holds the whole vectors of the clients
+    k = r (mod R) only; partial steps, RCCL reduce-scatter, optimizer and apply on the own blocks,
+    all-gather (ShardedFlatAggregator.round_whole).  Consumes the same client bytes per step."""
+
+    def __init__(self, wl, world, rank):
+        from appfl_amd import ops, workloads as W
+        from appfl_amd.sharded import ShardedFlatAggregator
+        rows = wl["table"]()
+        n = self.n_total = W.numel([r for r in rows if r[2] == torch.float32 and r[3]])
+        K = self.K = wl["K"]
+        opt = _OPT_OF[wl["cls"]]
+        cfg = W.EXAMPLE_CONFIGS[wl["cls"]]
+        hp = dict(lr=cfg.get("server_learning_rate", 0.0), tau=cfg.get("server_adapt_param", 0.0),
+                  beta1=cfg.get("server_momentum_param_1", 0.0),
+                  beta2=cfg.get("server_momentum_param_2", 0.0))
+        self.agg = ShardedFlatAggregator(n, opt, **hp)
+        dev = self.agg.g.device
+        base = torch.empty(n, dtype=torch.float32, device=dev)
+        ops.synth_fill(base, 7, scale=0.05)
+        self.agg.load_global(base)
+        mine = [k for k in range(K) if k % world == rank]
+        self.slab = torch.empty((max(len(mine), 1), n), dtype=torch.float32, device=dev)
+        for i, k in enumerate(mine):
+            ops.synth_fill(self.slab[i], 1000 + k, scale=0.01, base=base)
+        del base
+        self.rows = [self.slab[i] for i in range(len(mine))]
+        self.weights = [1.0 / K] * len(mine)
+        self.client_bytes = 4 * len(mine) * n
+
+    def step(self, events=None):
+        self.agg.round_whole(self.rows, self.weights)
+
+
 def time_steps(step, steps, warmup, barrier, use_dist, with_events=True):
     """`warmup` untimed steps, then `steps` steps between barriers; returns (seconds -- the max
     over ranks --, sorted per-step kernel ms from events on the launch stream)."""
@@ -616,9 +656,10 @@ def measure_cold(wl, name, steps, warmup, barrier):
     sets = SyncBench.cold_sets_for(wl)
     b = SyncBench(wl, 0, cold_sets=sets)
     elapsed, kernel_ms = time_steps(b.step, steps, max(warmup, sets), barrier, False)
-    r = roofline_of(b, kernel_ms, name)
+    r = roofline_of(b, kernel_ms, name + "_cold")
     out = {"frac_cold": r["frac"], "kernel_avg_ms_cold": r["kernel_avg_ms"],
            "kernel_min_ms_cold": r["kernel_min_ms"], "achieved_cold": r["achieved"],
+           "traffic_cold": r["traffic"],
            "value_cold": round(b.client_bytes * steps / elapsed / 1e9, 2),
            "ms_per_step_cold": round(elapsed / steps * 1e3, 4), "state_sets": sets}
     del b
@@ -662,15 +703,26 @@ def measure_sharded(name, wl, world, rank, steps, warmup, barrier, use_dist):
     def form(el):
         return {"value": round(total_client * steps / el / 1e9, 2), "unit": "GB/s",
                 "ms_per_step": round(el / steps * 1e3, 4)}
-    out = {"forms": {"no_collective": form(el_loc), "allgather": form(el_seq),
-                     "allgather_pipelined": form(elapsed)},
-           "roofline": roofline_of(b, kernel_ms, name),
-           "config": {"params_total": b.n_total, "params_per_gpu": b.map.n_local,
-                      "client_bytes_per_step_total": int(total_client),
-                      "block_rows": b.map.pieces, "block_elements": b.map.per,
-                      "gathered_bytes_per_gpu": 4 * b.map.P}}
+    forms = {"no_collective": form(el_loc), "allgather": form(el_seq), "allgather_pipelined": form(elapsed)}
+    geometry = (b.n_total, b.map.n_local, b.map.pieces, b.map.per, b.map.P)
+    roof = roofline_of(b, kernel_ms, name)
     del b
     torch.cuda.empty_cache()
+    # the whole-update mode (reduce-scatter + all-gather) on the same clients, where it fits
+    try:
+        wb = WholeUpdateBench(wl, world, rank)
+        el_whole, _ = time_steps(wb.step, steps, 2, barrier, use_dist, False)
+        forms["reduce_scatter_whole_updates"] = form(el_whole)
+        del wb
+    except (RuntimeError, MemoryError) as e:
+        forms["reduce_scatter_whole_updates"] = {"skipped": str(e)[:200]}
+    torch.cuda.empty_cache()
+    out = {"forms": forms,
+           "roofline": roof,
+           "config": {"params_total": geometry[0], "params_per_gpu": geometry[1],
+                      "client_bytes_per_step_total": int(total_client),
+                      "block_rows": geometry[2], "block_elements": geometry[3],
+                      "gathered_bytes_per_gpu": 4 * geometry[4]}}
     return out
 
 
@@ -765,8 +817,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    b = bench_class(wl)(wl, rank)
-    elapsed, kernel_ms = time_steps(b.step, a.steps, a.warmup, barrier, use_dist)
+    if a.tune_stash is not None:
+        from appfl_amd import ops
+        ops.tune(stash=a.tune_stash)
+    cold_only = a.cold and a.only and bench_class(wl) is SyncBench
+    if cold_only:
+        sets = SyncBench.cold_sets_for(wl)
+        b = SyncBench(wl, rank, cold_sets=sets)
+        elapsed, kernel_ms = time_steps(b.step, a.steps, max(a.warmup, sets), barrier, use_dist)
+    else:
+        b = bench_class(wl)(wl, rank)
+        elapsed, kernel_ms = time_steps(b.step, a.steps, a.warmup, barrier, use_dist)
     if rank == 0:
         out = {
             "metric": METRIC,
@@ -785,16 +846,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "aggregator": wl["cls"], "clients": wl["K"],
                        "params_per_gpu": b.result_numel, "client_bytes_per_step_per_gpu": b.client_bytes,
-                       "parallelism": "one GPU"},
+                       "parallelism": "one GPU",
+                       "state": f"cold: rotated over {len(b.sets)} independent sets" if cold_only
+                                else "re-used every step"},
             "roofline": roofline_of(b, kernel_ms, name),
         }
         del b
         torch.cuda.empty_cache()
-        if name in COLD_WORKLOADS or (bench_class(wl) is SyncBench and not a.only):
+        if not cold_only and (name in COLD_WORKLOADS or (bench_class(wl) is SyncBench and not a.only)) \
+                and not (a.only and a.tune_stash is not None):
             cold = measure_cold(wl, name, a.steps, a.warmup, barrier)
             out["roofline"].update({k: cold[k] for k in ("frac_cold", "kernel_avg_ms_cold",
                                                            "kernel_min_ms_cold", "achieved_cold",
-                                                           "state_sets")})
+                                                           "traffic_cold", "state_sets")})
             out["value_cold"], out["ms_per_step_cold"] = cold["value_cold"], cold["ms_per_step_cold"]
         if not a.only:
             extra = []

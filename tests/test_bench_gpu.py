@@ -39,6 +39,7 @@ def test_one_rank_nccl_run_reports_the_three_sharded_forms():
     for form in ("no_collective", "allgather", "allgather_pipelined"):
         assert out[form]["value"] > 0 and out[form]["ms_per_step"] > 0
     assert out["value"] == out["allgather_pipelined"]["value"]
+    assert out["reduce_scatter_whole_updates"]["value"] > 0           # the whole-update mode, same clients
     assert out["config"]["params_total"] == 25557032                # parameters, without BN statistics
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1

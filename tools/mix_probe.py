@@ -1,6 +1,6 @@
 """Development tool: times fa_weighted_mix (FedCompass / FedQueue combine) over flat device rows.
 
-    python tools/mix_probe.py [n] [K,K,...]
+    python tools/mix_probe.py [n] [K,K,...] [vptxunroll,...]   (0x8 = the default routing)
 """
 import os
 import sys
@@ -23,21 +23,27 @@ def main():
             ops.synth_fill(slab[k], 1000 + k, scale=0.01, base=g, n=n)
         rows = [slab[k] for k in range(K)]
         w = [0.5 / K] * K
+        shapes = [tuple(int(t) for t in sh.split("x")) for sh in sys.argv[3].split(",")] if len(sys.argv) > 3 else [(0, 8)]
         for mode, streams in (("replace", K + 1), ("convex", K + 2)):
-            def call():
-                ops.weighted_mix(rows, w, g, mode, coeff=0.5, n=n)
-            for _ in range(3):
-                call()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(20):
-                call()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 20
-            print(f"n={n} K={K:3d} {mode:8s} {ms:.4f} ms  {4 * streams * n / ms / 1e9:.3f} TB/s "
-                  f"({4 * streams * n / ms / 8e9:.3f} of peak)", flush=True)
+            line = f"n={n} K={K:3d} {mode:8s}"
+            for vpt, unroll in shapes:
+                ops.tune(vpt=vpt, unroll=unroll)
+
+                def call():
+                    ops.weighted_mix(rows, w, g, mode, coeff=0.5, n=n)
+                for _ in range(3):
+                    call()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(20):
+                    call()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 20
+                line += f"  [{vpt}x{unroll}] {ms:.4f} ms {4 * streams * n / ms / 8e9:.3f}"
+            ops.tune()
+            print(line, flush=True)
 
 
 if __name__ == "__main__":
