@@ -956,6 +956,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
 #ifndef FA_LATE_BATCH
 #define FA_LATE_BATCH 3
 #endif
+#ifndef FA_LATE_DEBUG
+#define FA_LATE_DEBUG 0   /* 1-3: timing experiments that drop parts of the epilogue (wrong results) */
+#endif
 constexpr int kLateBatch = FA_LATE_BATCH;   // tiles whose g / m / v the epilogue requests at once
 constexpr unsigned kLatePhaseTiles = 6;
 
@@ -1043,9 +1046,15 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceAr
                     for (int p = 0; p < VPT; ++p) {
                         bool live;
                         const unsigned i = tile_index(first + jj, p, live);
+#if FA_LATE_DEBUG == 3   /* timing experiment: no epilogue loads */
+                        gq[b][t][p] = Pack<4>{{1.0f, 2.0f, 3.0f, float(i)}};
+                        vq[b][t][p] = gq[b][t][p];
+                        if (kHasM) mq[b][t][p] = gq[b][t][p];
+#else
                         gq[b][t][p] = load_state<4>(a.g, i);
                         vq[b][t][p] = kHasM ? load_stream<4, true>(a.v, i) : load_state<4>(a.v, i);
                         if (kHasM) mq[b][t][p] = load_stream<4, true>(a.m, i);
+#endif
                     }
                 }
             };
@@ -1068,7 +1077,11 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceAr
                             if (kHasM) mq[b][t][p].e[e] = mj;
                             gq[b][t][p].e[e] = gq[b][t][p].e[e] + step;
                         }
+#if FA_LATE_DEBUG == 2   /* timing experiment: no epilogue stores (the impossible test keeps the values alive) */
+                        if (live && gq[b][t][p].e[0] == 1.2345e38f && vq[b][t][p].e[1] == 5.4321e37f && (!kHasM || mq[b][t][p].e[2] == 3.3e36f)) {
+#else
                         if (live) {
+#endif
                             burst_store(a.g, nbytes, i, as_f4(gq[b][t][p]));
                             burst_store(a.v, nbytes, i, as_f4(vq[b][t][p]));
                             if (kHasM) burst_store(a.m, nbytes, i, as_f4(mq[b][t][p]));
@@ -1078,9 +1091,12 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceAr
             };
             using B0 = std::integral_constant<int, 0>;
             using B1 = std::integral_constant<int, 1>;
+#if FA_LATE_DEBUG == 1   /* timing experiment: no epilogue at all */
+            if (a.n == 0xFFFFFFFFu)
+#endif
             fetch(j_lo, B0{});
 #pragma unroll 1
-            for (int jj = j_lo; jj <= j; jj += 2 * B) {
+            for (int jj = j_lo; jj <= j && FA_LATE_DEBUG != 1; jj += 2 * B) {
                 if (jj + B <= j) fetch(jj + B, B1{});
                 finish(jj, B0{});
                 if (jj + B <= j) {

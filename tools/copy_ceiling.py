@@ -33,3 +33,14 @@ for name, fn, streams in (("copy z = x", lambda: z.copy_(x), 2),
                           ("sum of x (read only)", lambda: x.sum(), 1)):
     t = timed(fn)
     print(f"{name:24s} {t:.4f} ms  {streams * n * 4 / t / 1e9:.2f} TB/s ({streams * n * 4 / t / 8e9:.3f} of peak)")
+
+# the library's own write-only kernel (write-through 128-bit stores are not used by fa_fill_f32;
+# plain stores) and its read-only synthetic check, for the write-bandwidth model in the design notes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from appfl_amd import ops  # noqa: E402
+
+t = timed(lambda: ops.fill(z, 1.5))
+print(f"{'ops.fill (write only)':24s} {t:.4f} ms  {n * 4 / t / 1e9:.2f} TB/s ({n * 4 / t / 8e9:.3f} of peak)")
