@@ -31,8 +31,7 @@ def timed(fn, reps=15):
 def main():
     cfgs = sys.argv[1] if len(sys.argv) > 1 else ";".join(
         f"25557032,{K},adam" for K in (16, 24, 32, 48, 64))
-    # phase lengths in tiles (0: the kernel's default); a trailing "p" = two 128-thread blocks per CU
-    phases = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"]
+    phases = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
     for cfg in cfgs.split(";"):
         n, K, opt = cfg.split(",")
         n, K = int(n), int(K)
@@ -64,16 +63,10 @@ def main():
         name = ops.reduce_kernel_name(K, n, opt)
         t_def = timed(lambda: run(*st))
         line = f"n={n} K={K} {opt}: default ({name}) {t_def:.4f} ms frac {alg / t_def / 8e9:.3f};"
-        for spec in phases:
-            paired = spec.endswith("p")
-            ph = int(spec.rstrip("p"))
-            ops.tune(stash=-3, nt=1 | (ph << 8) | (int(paired) << 13))
-            if paired:      # the bits must not depend on the block shape either
-                c = state()
-                run(*c), run(*c)
-                same = same and all(torch.equal(x, y) for x, y in zip(a, c))
+        for ph in phases:
+            ops.tune(stash=-3, nt=1 | (ph << 8))
             t = timed(lambda: run(*st))
-            line += f" late[{spec}] {t:.4f} ms frac {alg / t / 8e9:.3f} ({(t / t_def - 1) * 100:+.1f} %);"
+            line += f" late[{ph or 10} tiles] {t:.4f} ms frac {alg / t / 8e9:.3f} ({(t / t_def - 1) * 100:+.1f} %);"
         ops.tune()
         print(line + f" same bits: {same}", flush=True)
         del slab, xs, g0, a, b, st
