@@ -209,6 +209,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             for n, t in init.items():
                 self._layout.view(self._flats, n).copy_(t.detach())
         self._slab = ClientSlab(self._layout, self.device)
+        self._round_plans.clear()        # they point into the state vectors just replaced
 
     def _adopt_streamed_state(self) -> None:
         """A whole-model round after streamed rounds only: the global state is what the chunks
@@ -220,6 +221,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         for n, t in init.items():
             self._layout.view(self._flats, n).copy_(t)
         self._slab = ClientSlab(self._layout, self.device)
+        self._round_plans.clear()
 
     def _download(self, names=None) -> Dict[str, torch.Tensor]:
         """Fresh CPU copy of the global state: one D2H copy per dtype, entries are views of it."""

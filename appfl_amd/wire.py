@@ -26,7 +26,6 @@ import io
 import pickle
 import struct
 import warnings
-import zipfile
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 from typing import Any, Dict, Tuple, Union
@@ -93,52 +92,77 @@ class _Unpickler(pickle.Unpickler):
         return _StorageRef(str(pid[2]), pid[1].dtype, int(pid[4]))
 
 
-class _BufferFile:
-    """Read-only, seekable file over a memoryview -- just enough for zipfile to find the central
-    directory without copying the archive (io.BytesIO would copy all of it)."""
-
-    def __init__(self, buf: memoryview):
-        self._buf, self._pos = buf, 0
-
-    def seekable(self):
-        return True
-
-    def readable(self):
-        return True
-
-    def tell(self):
-        return self._pos
-
-    def seek(self, off, whence=0):
-        base = 0 if whence == 0 else (self._pos if whence == 1 else len(self._buf))
-        self._pos = max(0, base + off)
-        return self._pos
-
-    def read(self, n=-1):
-        end = len(self._buf) if n is None or n < 0 else min(len(self._buf), self._pos + n)
-        out = bytes(self._buf[self._pos:end])
-        self._pos = max(self._pos, end)
-        return out
-
-    def close(self):
-        pass
+_EOCD = struct.Struct("<IHHHHIIH")          # end of central directory record
+_EOCD64_LOC = struct.Struct("<IIQI")        # zip64 locator
+_EOCD64 = struct.Struct("<IQHHIIQQQQ")      # zip64 end of central directory
+_CDIR = struct.Struct("<IHHHHHHIIIHHHHHII")  # central directory file header
 
 
-def _stored_range(buf: memoryview, info: zipfile.ZipInfo) -> Tuple[int, int]:
-    """Byte range of an uncompressed member inside the archive buffer."""
-    if info.compress_type != zipfile.ZIP_STORED:
-        raise WireFormatError("compressed archive members are not supported")
-    h = info.header_offset
-    if h < 0 or info.file_size < 0 or h + 30 > len(buf):
-        raise WireFormatError("archive member outside the buffer")
-    sig, = struct.unpack_from("<I", buf, h)
-    if sig != 0x04034B50:
-        raise WireFormatError("bad local file header")
-    name_len, extra_len = struct.unpack_from("<HH", buf, h + 26)
-    start = h + 30 + name_len + extra_len
-    if start + info.file_size > len(buf):
-        raise WireFormatError("archive member reaches past the buffer")
-    return start, start + info.file_size
+def _members(buf: memoryview) -> Dict[str, Tuple[int, int]]:
+    """{member name: (start, end)} of the STORED members of a zip archive held in `buf`: the
+    central directory is walked directly (no per-member objects, no copy of the archive);
+    `torch.save` writes every record uncompressed.  Raises WireFormatError for anything else."""
+    n = len(buf)
+    if n < _EOCD.size:
+        raise WireFormatError("not a torch.save zip archive (legacy formats are not supported)")
+    # the end record sits at the very end unless the archive carries a comment (torch.save writes none)
+    tail_from = max(0, n - (_EOCD.size + 65535))
+    tail = bytes(buf[tail_from:])
+    at = tail.rfind(b"PK\x05\x06")
+    if at < 0:
+        raise WireFormatError("not a torch.save zip archive (legacy formats are not supported)")
+    eocd = tail_from + at
+    (_, _, _, _, count, cd_size, cd_off, _) = _EOCD.unpack_from(buf, eocd)
+    if count == 0xFFFF or cd_size == 0xFFFFFFFF or cd_off == 0xFFFFFFFF:
+        loc = eocd - _EOCD64_LOC.size
+        if loc < 0:
+            raise WireFormatError("truncated zip64 archive")
+        sig, _, eocd64, _ = _EOCD64_LOC.unpack_from(buf, loc)
+        if sig != 0x07064B50 or eocd64 + _EOCD64.size > n:
+            raise WireFormatError("bad zip64 locator")
+        (sig, _, _, _, _, _, _, count, cd_size, cd_off) = _EOCD64.unpack_from(buf, eocd64)
+        if sig != 0x06064B50:
+            raise WireFormatError("bad zip64 end record")
+    if cd_off + cd_size > n:
+        raise WireFormatError("central directory outside the buffer")
+    out: Dict[str, Tuple[int, int]] = {}
+    pos = cd_off
+    unpack_cd, unpack_lh = _CDIR.unpack_from, struct.Struct("<IHHHHHIIIHH").unpack_from
+    for _ in range(count):
+        (sig, _, _, _, method, _, _, _, csize, usize, name_len, extra_len, comment_len, _, _, _,
+         header) = unpack_cd(buf, pos)
+        if sig != 0x02014B50:
+            raise WireFormatError("bad central directory entry")
+        name = bytes(buf[pos + 46:pos + 46 + name_len]).decode("utf-8")
+        if usize == 0xFFFFFFFF or csize == 0xFFFFFFFF or header == 0xFFFFFFFF:
+            # zip64 extra field: the 64-bit values, in this order, for the fields that overflowed
+            ex, ex_end = pos + 46 + name_len, pos + 46 + name_len + extra_len
+            while ex + 4 <= ex_end:
+                tag, size = struct.unpack_from("<HH", buf, ex)
+                if tag == 1:
+                    vals = struct.unpack_from("<%dQ" % (size // 8), buf, ex + 4)
+                    it = iter(vals)
+                    if usize == 0xFFFFFFFF:
+                        usize = next(it)
+                    if csize == 0xFFFFFFFF:
+                        csize = next(it)
+                    if header == 0xFFFFFFFF:
+                        header = next(it)
+                    break
+                ex += 4 + size
+        pos += 46 + name_len + extra_len + comment_len
+        if method != 0 or csize != usize:
+            raise WireFormatError("compressed archive members are not supported")
+        if header + 30 > n:
+            raise WireFormatError("archive member outside the buffer")
+        lh = unpack_lh(buf, header)
+        if lh[0] != 0x04034B50:
+            raise WireFormatError("bad local file header")
+        start = header + 30 + lh[9] + lh[10]
+        if start + usize > n:
+            raise WireFormatError("archive member reaches past the buffer")
+        out[name] = (start, start + usize)
+    return out
 
 
 def _contiguous(size, stride) -> bool:
@@ -159,7 +183,7 @@ def bytes_to_model(model_bytes: Union[bytes, bytearray, memoryview]) -> Dict[str
         return _bytes_to_model(memoryview(model_bytes).cast("B"))
     except WireFormatError:
         raise
-    except (struct.error, pickle.UnpicklingError, zipfile.BadZipFile, zipfile.LargeZipFile, EOFError,
+    except (struct.error, pickle.UnpicklingError, UnicodeDecodeError, StopIteration, EOFError,
             AttributeError, IndexError, KeyError, TypeError, ValueError, RuntimeError, OverflowError,
             NotImplementedError) as e:
         # malformed or unusual archives must take the caller's safe fallback, not escape
@@ -167,16 +191,12 @@ def bytes_to_model(model_bytes: Union[bytes, bytearray, memoryview]) -> Dict[str
 
 
 def _bytes_to_model(buf: memoryview) -> Dict[str, torch.Tensor]:
-    try:
-        zf = zipfile.ZipFile(_BufferFile(buf))
-    except zipfile.BadZipFile as e:
-        raise WireFormatError("not a torch.save zip archive (legacy formats are not supported)") from e
-    members = {i.filename: i for i in zf.infolist()}
+    members = _members(buf)
     pkl = [n for n in members if n.endswith("/data.pkl") or n == "data.pkl"]
     if len(pkl) != 1:
         raise WireFormatError("archive has no data.pkl")
     prefix = pkl[0][: -len("data.pkl")]
-    a, b = _stored_range(buf, members[pkl[0]])
+    a, b = members[pkl[0]]
     obj = _Unpickler(io.BytesIO(buf[a:b])).load()
     if not isinstance(obj, dict):
         raise WireFormatError(f"expected a state dict, got {type(obj).__name__}")
@@ -188,37 +208,49 @@ def _bytes_to_model(buf: memoryview) -> Dict[str, torch.Tensor]:
     return out
 
 
+_ITEMSIZE = {dt: torch.empty((), dtype=dt).element_size() for dt in _STORAGE_DTYPES.values()}
+
+
 def _fill_views(out, obj, buf, members, prefix) -> None:
+    data_prefix = prefix + "data/"
+    frombuffer = torch.frombuffer
     for name, ref in obj.items():
         if not isinstance(ref, _TensorRef):
             raise WireFormatError(f"entry {name!r} is not a tensor")
-        member = members.get(f"{prefix}data/{ref.storage.key}")
-        if member is None:
-            raise WireFormatError(f"storage {ref.storage.key} missing from the archive")
-        s0, s1 = _stored_range(buf, member)
-        if (ref.storage.numel < 0 or ref.offset < 0 or any(d < 0 for d in ref.size)
-                or any(d < 0 for d in ref.stride) or len(ref.size) != len(ref.stride)):
+        storage = ref.storage
+        span = members.get(data_prefix + storage.key)
+        if span is None:
+            raise WireFormatError(f"storage {storage.key} missing from the archive")
+        s0, s1 = span
+        size, stride = ref.size, ref.stride
+        if storage.numel < 0 or ref.offset < 0 or len(size) != len(stride):
             raise WireFormatError(f"entry {name!r} has a negative or inconsistent size, stride or offset")
-        item = torch.empty((), dtype=ref.storage.dtype).element_size()
-        if s1 - s0 < ref.storage.numel * item:
-            raise WireFormatError(f"storage {ref.storage.key} is truncated")
         numel = 1
-        for s in ref.size:
-            numel *= s
+        for d in size:
+            if d < 0:
+                raise WireFormatError(f"entry {name!r} has a negative or inconsistent size, stride or offset")
+            numel *= d
+        for d in stride:
+            if d < 0:
+                raise WireFormatError(f"entry {name!r} has a negative or inconsistent size, stride or offset")
+        dtype = storage.dtype
+        item = _ITEMSIZE[dtype]
+        if s1 - s0 < storage.numel * item:
+            raise WireFormatError(f"storage {storage.key} is truncated")
         start = s0 + ref.offset * item
         if numel == 0:
-            out[name] = torch.empty(ref.size, dtype=ref.storage.dtype)
-        elif _contiguous(ref.size, ref.stride):
+            out[name] = torch.empty(size, dtype=dtype)
+        elif _contiguous(size, stride):
             if start + numel * item > s1:
                 raise WireFormatError(f"entry {name!r} reaches past its storage")
-            t = torch.frombuffer(buf, dtype=ref.storage.dtype, count=numel, offset=start)
-            out[name] = t.view(ref.size)
+            t = frombuffer(buf, dtype=dtype, count=numel, offset=start)
+            out[name] = t.view(size) if len(size) != 1 else t
         else:
-            last = ref.offset + sum((d - 1) * st for d, st in zip(ref.size, ref.stride))
-            if last >= ref.storage.numel:
+            last = ref.offset + sum((d - 1) * st for d, st in zip(size, stride))
+            if last >= storage.numel:
                 raise WireFormatError(f"entry {name!r} reaches past its storage")
-            whole = torch.frombuffer(buf, dtype=ref.storage.dtype, count=ref.storage.numel, offset=s0)
-            out[name] = torch.as_strided(whole, ref.size, ref.stride, ref.offset).clone()
+            whole = frombuffer(buf, dtype=dtype, count=storage.numel, offset=s0)
+            out[name] = torch.as_strided(whole, size, stride, ref.offset).clone()
 
 
 # ---------------------------------------------------------------------------------------------

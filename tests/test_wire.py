@@ -97,9 +97,11 @@ def test_written_archive_loads_with_torch_load_and_has_valid_checksums():
     names = lambda b: sorted(i.filename for i in zipfile.ZipFile(io.BytesIO(b)).infolist()
                              if "serialization_id" not in i.filename)
     assert names(raw) == names(ref.getvalue())
-    for i in zipfile.ZipFile(io.BytesIO(raw)).infolist():
-        a, _ = wire._stored_range(memoryview(raw), i)
-        assert a % 64 == 0, i.filename
+    spans = wire._members(memoryview(raw))
+    assert sorted(spans) == sorted(i.filename for i in zipfile.ZipFile(io.BytesIO(raw)).infolist())
+    for name, (a, b) in spans.items():
+        assert a % 64 == 0, name
+        assert bytes(raw[a:b]) == zipfile.ZipFile(io.BytesIO(raw)).read(name), name   # the walk agrees with zipfile
 
 
 def test_large_record_is_checksummed_in_chunks():
@@ -144,3 +146,31 @@ def test_corrupted_archives_raise_wire_format_error_only():
             continue
         # a corruption that happens to leave a readable archive must still give tensors
         assert all(isinstance(t, torch.Tensor) for t in out.values())
+
+
+def test_archive_walk_reads_zip64_records():
+    """Archives beyond 4 GiB (a 1.3 B-parameter update is 5.2 GB) carry their sizes and offsets in
+    zip64 records; a hand-built miniature with every field overflowed must walk the same way."""
+    import struct
+    payload = b"0123456789abcdef" * 3
+    name = b"archive/data/0"
+    local = struct.pack("<IHHHHHIIIHH", 0x04034B50, 45, 0, 0, 0, 0, 0, 0xFFFFFFFF, 0xFFFFFFFF, len(name), 20)
+    local += name + struct.pack("<HHQQ", 1, 16, len(payload), len(payload))
+    body = b"\0" * 7 + local + payload                 # the member does not start at offset 0
+    header_at = 7
+    extra = struct.pack("<HHQQQ", 1, 24, len(payload), len(payload), header_at)
+    cdir = struct.pack("<IHHHHHHIIIHHHHHII", 0x02014B50, 45, 45, 0, 0, 0, 0, 0, 0xFFFFFFFF, 0xFFFFFFFF,
+                       len(name), len(extra), 0, 0, 0, 0, 0xFFFFFFFF) + name + extra
+    cd_off = len(body)
+    eocd64 = struct.pack("<IQHHIIQQQQ", 0x06064B50, 44, 45, 45, 0, 0, 1, 1, len(cdir), cd_off)
+    locator = struct.pack("<IIQI", 0x07064B50, 0, cd_off + len(cdir), 1)
+    eocd = struct.pack("<IHHHHIIH", 0x06054B50, 0, 0, 0xFFFF, 0xFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0)
+    raw = body + cdir + eocd64 + locator + eocd
+    spans = wire._members(memoryview(raw))
+    assert list(spans) == ["archive/data/0"]
+    a, b = spans["archive/data/0"]
+    assert raw[a:b] == payload
+    # a directory entry pointing outside the buffer is refused, not followed
+    bad = raw.replace(struct.pack("<Q", header_at), struct.pack("<Q", 10 ** 9), 1)
+    with pytest.raises(wire.WireFormatError):
+        wire._members(memoryview(bad))
