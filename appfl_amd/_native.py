@@ -87,6 +87,7 @@ SIGNATURES = {
     "fa_pack_host": (_i, [_p, _p, _p, _p, _i, _i]),
     "fa_pack_host_window": (_i, [_p, _p, _p, _p, _i, _sz, _sz, _i]),
     "fa_host_copy_fresh": (_i, [_p, _p, _sz, _i]),
+    "fa_host_copy_crc32": (_i, [_p, _p, _sz, _sz, _p, _i]),
 }
 
 

@@ -2626,6 +2626,85 @@ int fa_pack_host_window(void* dst, const void* const* src, const size_t* dst_off
     return fa_pack_host(dst, s2.data(), o2.data(), n2.data(), static_cast<int>(s2.size()), threads);
 }
 
+namespace {
+
+// CRC-32 (the zip / zlib polynomial, reflected) by eight table look-ups per 8 bytes.
+uint32_t g_crc_table[8][256];
+std::once_flag g_crc_once;
+
+void crc_tables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        g_crc_table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t)
+            g_crc_table[t][i] = (g_crc_table[t - 1][i] >> 8) ^ g_crc_table[0][g_crc_table[t - 1][i] & 0xFFu];
+}
+
+// Copies [src, src + n) to dst and returns the CRC-32 of the bytes (one pass over the source).
+uint32_t copy_crc32(unsigned char* dst, const unsigned char* src, size_t n) {
+    uint32_t c = 0xFFFFFFFFu;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, src + i, 8);
+        memcpy(dst + i, &w, 8);
+        const uint32_t lo = static_cast<uint32_t>(w) ^ c, hi = static_cast<uint32_t>(w >> 32);
+        c = g_crc_table[7][lo & 0xFFu] ^ g_crc_table[6][(lo >> 8) & 0xFFu] ^ g_crc_table[5][(lo >> 16) & 0xFFu] ^
+            g_crc_table[4][lo >> 24] ^ g_crc_table[3][hi & 0xFFu] ^ g_crc_table[2][(hi >> 8) & 0xFFu] ^
+            g_crc_table[1][(hi >> 16) & 0xFFu] ^ g_crc_table[0][hi >> 24];
+    }
+    for (; i < n; ++i) {
+        dst[i] = src[i];
+        c = g_crc_table[0][(c ^ src[i]) & 0xFFu] ^ (c >> 8);
+    }
+    return c ^ 0xFFFFFFFFu;
+}
+
+}  // namespace
+
+int fa_host_copy_crc32(void* dst, const void* src, size_t nbytes, size_t chunk, uint32_t* crcs,
+                       int threads) {
+    if (!dst || !src || !crcs || chunk == 0) return FA_ERR_INVALID;
+    if (!nbytes) return FA_OK;
+    std::call_once(g_crc_once, crc_tables);
+    const size_t chunks = (nbytes + chunk - 1) / chunk;
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if (static_cast<size_t>(threads) > chunks) threads = static_cast<int>(chunks);
+    std::atomic<size_t> next{0};
+    auto work = [&](int) {
+        for (;;) {
+            const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= chunks) return;
+            const size_t a = c * chunk, n = (nbytes - a < chunk) ? nbytes - a : chunk;
+            crcs[c] = copy_crc32(static_cast<unsigned char*>(dst) + a, static_cast<const unsigned char*>(src) + a, n);
+        }
+    };
+    if (threads == 1) {
+        work(0);
+        return FA_OK;
+    }
+    {
+        std::unique_lock<std::mutex> mine(g_pack_pool_busy, std::try_to_lock);
+        if (mine.owns_lock()) {
+            PackPool* pool = pack_pool();
+            if (pool && threads <= pool->workers() + 1) {
+                pool->run(threads, work);
+                return FA_OK;
+            }
+        }
+    }
+    std::vector<std::thread> own;
+    own.reserve(static_cast<size_t>(threads));
+    for (int j = 1; j < threads; ++j) own.emplace_back(work, j);
+    work(0);
+    for (auto& th : own) th.join();
+    return FA_OK;
+}
+
 int fa_host_copy_fresh(void* dst, const void* src, size_t nbytes, int threads) {
     if ((!dst || !src) && nbytes) return FA_ERR_INVALID;
     if (!nbytes) return FA_OK;

@@ -262,6 +262,19 @@ _CHUNK = 8 << 20                 # bytes per copy / CRC task
 WRITE_THREADS = 8
 
 
+_NATIVE_CHUNK = 1 << 20          # bytes per CRC piece of the native fused copy
+
+
+def _native_copy_crc32():
+    """`fa_host_copy_crc32` of the device library when it is built (host code only: no GPU is
+    touched), else None -- serialising a state dict must also work where only this module is used."""
+    try:
+        from . import _native
+        return _native.load().fa_host_copy_crc32
+    except Exception:
+        return None
+
+
 class _StorageMarker:
     def __init__(self, key: str, dtype: torch.dtype, numel: int):
         self.key, self.dtype, self.numel = key, dtype, numel
@@ -392,14 +405,28 @@ def model_to_bytes(state_dict: Dict[str, torch.Tensor], prefix: str = "archive")
     # uninitialised, so the pages are first touched by the copy threads rather than zero-filled
     view = np.empty(total, dtype=np.uint8)
     out = memoryview(view)
-    # payload pass: big records are copied and checksummed in chunks on a thread pool
+    # payload pass: big records are copied and checksummed in chunks -- by the native library's
+    # host threads in one fused pass where it is built, else on a Python thread pool
     tasks = []                       # (entry index, chunk start, chunk end)
     crcs = [0] * len(entries)
+    native = _native_copy_crc32()
     for i, (nm, size, at, pad, payload) in enumerate(entries):
         start = at + 30 + len(nm) + pad
         if isinstance(payload, bytes):
             out[start:start + size] = payload
             crcs[i] = zlib.crc32(payload)
+        elif native is not None and size >= (1 << 20):
+            import ctypes as C
+            n_chunks = (size + _NATIVE_CHUNK - 1) // _NATIVE_CHUNK
+            parts = (C.c_uint32 * n_chunks)()
+            rc = native(C.c_void_p(view.ctypes.data + start), C.c_void_p(payload.data_ptr()), size,
+                        _NATIVE_CHUNK, parts, WRITE_THREADS)
+            if rc != 0:
+                raise WireFormatError(f"fa_host_copy_crc32 failed ({rc})")
+            c = parts[0]
+            for k in range(1, n_chunks):
+                c = crc32_combine(c, parts[k], min(_NATIVE_CHUNK, size - k * _NATIVE_CHUNK))
+            crcs[i] = c
         else:
             for a in range(0, size, _CHUNK):
                 tasks.append((i, start, a, min(a + _CHUNK, size)))

@@ -416,6 +416,17 @@ int fa_pack_host_window(void* dst, const void* const* src, const size_t* dst_off
  */
 int fa_host_copy_fresh(void* dst, const void* src, size_t nbytes, int threads);
 
+/*
+ * Threaded copy of `nbytes` from `src` to `dst` that also yields the CRC-32 (zip polynomial) of
+ * every `chunk`-byte piece in the same pass: crcs[i] = crc32(src[i*chunk .. min((i+1)*chunk,
+ * nbytes))), ceil(nbytes / chunk) values.  All pointers are HOST memory.  For writing the new
+ * global model back into a torch.save-compatible archive, whose records carry a CRC-32
+ * (comm/mpi/serializer.py:46-50 model_to_byte, comm/grpc/utils.py:20-24 serialize_model: both
+ * torch.save, which checksums every record on one thread).
+ */
+int fa_host_copy_crc32(void* dst, const void* src, size_t nbytes, size_t chunk, uint32_t* crcs,
+                       int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,30 @@ def test_staleness_functions_and_their_errors():
     exp = fedqueue_staleness("exponential", beta=0.1)        # building it works, as in the reference
     with pytest.raises(TypeError):
         exp(2)
+
+
+def test_host_copy_crc32_matches_zlib_per_chunk():
+    """The fused threaded copy + CRC-32 of the archive writer: every piece's checksum is zlib's,
+    the copy is exact, for lengths around the 8-byte stride and the chunk boundaries, with one and
+    several threads; the pieces combine to the checksum of the whole."""
+    import zlib
+
+    from appfl_amd import wire
+    lib = N.load()
+    assert lib.fa_host_copy_crc32(None, None, 8, 4, None, 1) == -1
+    rng = np.random.default_rng(5)
+    for n, chunk, threads in [(1, 7, 1), (7, 8, 1), (8, 8, 2), (1000, 64, 3), (65537, 4096, 8),
+                              (3_000_001, 1 << 20, 8), (5_000_000, 1 << 20, 1)]:
+        src = rng.integers(0, 256, n, dtype=np.uint8)
+        dst = np.zeros(n + 8, np.uint8)
+        pieces = (n + chunk - 1) // chunk
+        crcs = (C.c_uint32 * pieces)()
+        rc = lib.fa_host_copy_crc32(C.c_void_p(dst.ctypes.data), C.c_void_p(src.ctypes.data), n, chunk, crcs, threads)
+        assert rc == 0
+        assert np.array_equal(dst[:n], src) and not dst[n:].any()
+        whole = 0
+        for i in range(pieces):
+            part = src[i * chunk:(i + 1) * chunk].tobytes()
+            assert crcs[i] == zlib.crc32(part), (n, chunk, i)
+            whole = crcs[i] if i == 0 else wire.crc32_combine(whole, crcs[i], len(part))
+        assert whole == zlib.crc32(src.tobytes())
