@@ -2670,6 +2670,13 @@ int fa_host_copy_crc32(void* dst, const void* src, size_t nbytes, size_t chunk, 
     if (!dst || !src || !crcs || chunk == 0) return FA_ERR_INVALID;
     if (!nbytes) return FA_OK;
     std::call_once(g_crc_once, crc_tables);
+    {
+        // the destination is usually a fresh allocation: ask for huge pages before its first touch
+        const uintptr_t page = 4096;
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(dst) + page - 1) & ~(page - 1);
+        const uintptr_t e = (reinterpret_cast<uintptr_t>(dst) + nbytes) & ~(page - 1);
+        if (e > a && e - a >= (size_t(4) << 20)) madvise(reinterpret_cast<void*>(a), e - a, MADV_HUGEPAGE);
+    }
     const size_t chunks = (nbytes + chunk - 1) / chunk;
     if (threads < 1) threads = 1;
     if (threads > 64) threads = 64;
