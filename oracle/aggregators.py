@@ -31,13 +31,20 @@ from typing import Any, Dict, Optional
 
 import numpy as np
 
+from . import halfarray
+
 F32 = np.float32
 _INT = (np.dtype(np.int64), np.dtype(np.int32))
 
 
 def to_np(t) -> np.ndarray:
-    if isinstance(t, np.ndarray):
+    """A tensor as the array type the formulas below run on: numpy for fp32 / fp64 / integers,
+    oracle.halfarray.HalfArray (fp32 carrier, every operation rounded to the 16-bit type, which
+    is what PyTorch's CPU kernels do) for bfloat16 / float16."""
+    if isinstance(t, (np.ndarray, halfarray.HalfArray)):
         return t
+    if str(t.dtype) in ("torch.bfloat16", "torch.float16"):
+        return halfarray.from_torch(t)
     return t.detach().cpu().numpy()
 
 
@@ -392,6 +399,9 @@ class OracleFedAsync(OracleBase):
 
     def _arrival_step(self, x, g, alpha_t, gradient_based, sub_form):
         a = _sc(alpha_t, g)
+        if sub_form and isinstance(g, halfarray.HalfArray):
+            # add_ / sub_(..., alpha=alpha_t) (:246-258) cast alpha to the tensor's own type first
+            a = halfarray.round_scalar(a, g.kind)
         if not gradient_based:
             return a * (x - g)                 # :253-258 / :263
         if sub_form:

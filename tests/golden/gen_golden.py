@@ -1,7 +1,8 @@
 """Generates tests/golden/golden.npz by running the REFERENCE aggregator classes (imported from
 /root/reference, never copied) over tests/scenarios.py.  Run in the build container only:
 
-    python tests/golden/gen_golden.py
+    python tests/golden/gen_golden.py            # golden.npz: every scenario but the 16-bit ones
+    python tests/golden/gen_golden.py --half     # golden_half.npz: the bfloat16 / float16 scenarios
 
 The reference needs `omegaconf` and `opacus` at import time, which are not installed here; two
 placeholder modules (a dict-with-attributes DictConfig, an empty PrivacyEngine) satisfy the
@@ -83,8 +84,9 @@ def main():
             return SyncScheduler(DictConfig({"num_clients": num_clients, "same_init_model": True}), agg, None)
         return AsyncScheduler(DictConfig({"num_clients": num_clients}), agg, None)
 
+    half = "--half" in sys.argv[1:]
     arrays, index = {}, {}
-    for sc in S.all_scenarios():
+    for sc in (S.half_scenarios() if half else S.base_scenarios()):
         if sc["kind"].startswith("sched"):
             rec = S.run_scenario(loader_factory, sc, schedulers)
         else:
@@ -101,7 +103,7 @@ def main():
         index[sc["id"]] = entries
         print(f"{sc['id']}: {len(rec)} records")
     arrays["__index__"] = np.frombuffer(json.dumps(index).encode(), dtype=np.uint8)
-    out = os.path.join(HERE, "golden.npz")
+    out = os.path.join(HERE, "golden_half.npz" if half else "golden.npz")
     np.savez_compressed(out, **arrays)
     print("wrote", out, os.path.getsize(out), "bytes,", len(index), "scenarios")
 

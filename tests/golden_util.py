@@ -1,4 +1,5 @@
-"""Loading and checking tests/golden/golden.npz (vectors produced by the reference's classes)."""
+"""Loading and checking tests/golden/golden.npz and golden_half.npz (vectors produced by the
+reference's classes)."""
 
 import hashlib
 import json
@@ -6,15 +7,33 @@ import os
 
 import numpy as np
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.npz")
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = os.path.join(_DIR, "golden.npz")
+GOLDEN_FILES = [GOLDEN, os.path.join(_DIR, "golden_half.npz")]
 _cache = {}
+
+
+class _Merged:
+    """The arrays of several .npz files behind one `files` / `[]` (scenario ids are unique)."""
+
+    def __init__(self, zs):
+        self._where = {}
+        for z in zs:
+            for f in z.files:
+                self._where[f] = z
+        self.files = set(self._where)
+
+    def __getitem__(self, key):
+        return self._where[key][key]
 
 
 def load():
     if "z" not in _cache:
-        z = np.load(GOLDEN, allow_pickle=False)
-        _cache["z"] = z
-        _cache["index"] = json.loads(bytes(z["__index__"]).decode())
+        zs = [np.load(f, allow_pickle=False) for f in GOLDEN_FILES]
+        index = {}
+        for z in zs:
+            index.update(json.loads(bytes(z["__index__"]).decode()))
+        _cache["z"], _cache["index"] = _Merged(zs), index
     return _cache["z"], _cache["index"]
 
 

@@ -53,6 +53,11 @@ MIXED64 = {
 # one large parameter with an odd element count and its bias (ADMM scenarios: 128-bit body + tail)
 LINEAR = {"l.weight": ((257, 1001), "f32"), "l.bias": ((257,), "f32")}
 SPECS = {"toy": TOY, "ragged": RAGGED, "big": BIG, "mixed64": MIXED64, "linear": LINEAR}
+# the same entries with every fp32 tensor held in bfloat16 / float16 instead
+HALF_KINDS = {"bf16": torch.bfloat16, "f16": torch.float16}
+for _kind in HALF_KINDS:
+    for _base in ("toy", "ragged"):
+        SPECS[f"{_base}_{_kind}"] = {n: (shp, _kind if k == "f32" else k) for n, (shp, k) in SPECS[_base].items()}
 
 _NP = {"f32": np.float32, "f64": np.float64, "i64": np.int64, "i32": np.int32}
 
@@ -114,7 +119,8 @@ class LinearModel(torch.nn.Module):
                 t.copy_(torch.from_numpy(synth.fill(t.numel(), 700 + i, scale=0.05).reshape(tuple(t.shape))))
 
 
-MODELS = {"toy": ToyModel, "mixed64": Mixed64Model, "linear": LinearModel}
+MODELS = {"toy": ToyModel, "mixed64": Mixed64Model, "linear": LinearModel,
+          "toy_bf16": lambda: ToyModel().to(torch.bfloat16), "toy_f16": lambda: ToyModel().to(torch.float16)}
 
 
 def _name_seed(name: str) -> int:
@@ -138,7 +144,7 @@ def make_state(spec: Dict, seed: int, base_seed: int = 7, scale: float = 0.02,
                 a[1] = 0.0 if gradient else fill64(n, base_seed * 131 + ns, scale=0.05)[1]
                 a[2] = -0.0
                 a[4] = 1e-310                       # a float64 denormal
-        elif kind == "f32":
+        elif kind in ("f32", "bf16", "f16"):
             if gradient:
                 a = synth.fill(n, seed * 131 + ns, scale=scale)
             else:
@@ -154,13 +160,24 @@ def make_state(spec: Dict, seed: int, base_seed: int = 7, scale: float = 0.02,
         else:
             a = synth.ints(seed * 131 + ns, n, -9, 10, _NP[kind])
         out[name] = torch.from_numpy(a.reshape(shape))
+        if kind in HALF_KINDS:          # rounded to the 16-bit type (3e30 is inf in float16)
+            out[name] = out[name].to(HALF_KINDS[kind])
     return out
 
 
 def _snap(d) -> Dict[str, np.ndarray]:
+    """Records hold numpy arrays; bfloat16 / float16 tensors (numpy has no bfloat16) are held as
+    their 16-bit patterns (uint16), every NaN as the type's one quiet NaN."""
     out = {}
     for k, v in d.items():
-        a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        if isinstance(v, torch.Tensor) and v.dtype in (torch.bfloat16, torch.float16):
+            v = v.detach().cpu().clone()
+            v[v.isnan()] = float("nan")
+            a = v.contiguous().view(torch.int16).numpy().view(np.uint16)
+        elif hasattr(v, "bits") and hasattr(v, "kind"):      # oracle.halfarray.HalfArray
+            a = v.bits()
+        else:
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
         out[k] = np.array(a, copy=True)
     return out
 
@@ -254,7 +271,11 @@ REFERENCE_RTOL = 1e-6
 
 
 def reference_rtol(sc: Dict):
-    """None = bit-exact against the reference's vectors; else max |diff| / max |tensor|."""
+    """None = bit-exact against the reference's vectors; else max |diff| / max |tensor|.
+    (bfloat16 / float16 scenarios are bit-exact throughout: a last-place difference of the fp32
+    sqrt disappears when the result is rounded to 8 or 11 significant bits.)"""
+    if sc.get("half"):
+        return None
     return REFERENCE_RTOL if sc["cls"] in SQRT_CLASSES else None
 
 
@@ -282,7 +303,7 @@ def chunked_scenarios() -> List[Dict]:
 
 def chunk_keys_by_size(spec: Dict, max_bytes: int) -> List[List[str]]:
     """misc/memory_utils.py:317-379: names sorted, greedy fill, oversized tensors alone."""
-    item = {"f32": 4, "f64": 8, "i64": 8, "i32": 4}
+    item = {"f32": 4, "f64": 8, "i64": 8, "i32": 4, "bf16": 2, "f16": 2}
     chunks, cur, size = [], [], 0
     for key in sorted(spec):
         shape, kind = spec[key]
@@ -448,10 +469,58 @@ def admm_scenarios() -> List[Dict]:
     return out
 
 
-def all_scenarios() -> List[Dict]:
+def half_scenarios() -> List[Dict]:
+    """bfloat16 / float16 state dicts (integer entries stay int64 / int32): the reference's float
+    path takes any float dtype (misc/memory_utils.py:112-131) and PyTorch then rounds every single
+    tensor operation to the 16-bit type.  Golden records in tests/golden/golden_half.npz."""
+    out = []
+    sizes = {c: 3 + 8 * c + (c % 3) for c in range(6)}
+    for kind in HALF_KINDS:
+        for cls, with_model in itertools.product(SYNC_CLASSES, (False, True)):
+            out.append({"id": f"{cls[:-10]}-{kind}-{'model' if with_model else 'nomodel'}", "kind": "sync",
+                        "cls": cls, "spec": f"toy_{kind}", "model": with_model,
+                        "cfg": dict(HP[cls], client_weights_mode="sample_size"), "rounds": [2, 4, 3],
+                        "sample_sizes": sizes})
+        for cls in ("FedAvgAggregator", "FedAdamAggregator", "FedYogiAggregator"):
+            out.append({"id": f"{cls[:-10]}-{kind}-ragged", "kind": "sync", "cls": cls,
+                        "spec": f"ragged_{kind}", "model": False,
+                        "cfg": dict(HP[cls], client_weights_mode="equal"), "rounds": [3, 5, 1],
+                        "sample_sizes": {}})
+        for gb, with_model, optmem in itertools.product((False, True), (False, True), (True, False)):
+            cfg = dict(STALENESS["polynomial"], alpha=0.9, num_clients=3, gradient_based=gb,
+                       optimize_memory=optmem)
+            out.append({"id": f"FedAsync-{kind}-{'grad' if gb else 'model'}-"
+                              f"{'model' if with_model else 'nomodel'}-{'opt' if optmem else 'orig'}",
+                        "kind": "async", "cls": "FedAsyncAggregator", "spec": f"toy_{kind}",
+                        "model": with_model, "cfg": cfg, "script": ASYNC_SCRIPT[:6], "sample_sizes": {}})
+        for gb, with_model in ((False, False), (True, True), (False, True)):
+            cfg = dict(STALENESS["hinge"], alpha=0.9, num_clients=3, K=2, gradient_based=gb)
+            out.append({"id": f"FedBuff-{kind}-{'grad' if gb else 'model'}-{'model' if with_model else 'nomodel'}",
+                        "kind": "async", "cls": "FedBuffAggregator",
+                        "spec": f"toy_{kind}" if with_model else f"ragged_{kind}", "model": with_model,
+                        "cfg": cfg, "script": ASYNC_SCRIPT[:6], "sample_sizes": {}})
+        out.append({"id": f"FedAvg-{kind}-chunked", "kind": "chunked", "cls": "FedAvgAggregator",
+                    "spec": f"toy_{kind}", "model": False,
+                    "cfg": dict(HP["FedAvgAggregator"], client_weights_mode="equal"),
+                    "rounds": [2, 3], "chunk_bytes": 300, "whole_after": [2], "sample_sizes": {}})
+        out.append({"id": f"FedAvgM-{kind}-getparams", "kind": "getparams", "cls": "FedAvgMAggregator",
+                    "spec": f"toy_{kind}", "model": True,
+                    "cfg": dict(HP["FedAvgMAggregator"], client_weights_mode="equal"),
+                    "chunk_bytes": [300, 10 ** 9], "rounds": [3, 2], "sample_sizes": {}})
+    for sc in out:
+        sc["half"] = True
+    return out
+
+
+def base_scenarios() -> List[Dict]:
+    """Everything whose golden records live in tests/golden/golden.npz."""
     return (sync_scenarios() + async_scenarios() + chunked_scenarios() + mix_scenarios()
             + secure_scenarios() + getparams_scenarios() + sched_scenarios() + float64_scenarios()
             + admm_scenarios())
+
+
+def all_scenarios() -> List[Dict]:
+    return base_scenarios() + half_scenarios()
 
 
 def _meta_record(meta: Dict) -> Dict[str, np.ndarray]:
