@@ -27,6 +27,7 @@ _u64 = C.c_uint64
 
 FA_DT_F32, FA_DT_I64, FA_DT_I32 = range(3)
 FA_ROUTE_DEFAULT, FA_ROUTE_NO_PERSISTENT = 0, 1
+FA_HALF_BF16, FA_HALF_F16 = 1, 2
 FA_ADMM_KCHUNK, FA_ADMM_BLOCKS = 64, 2048
 FA_ADMM_RES_WS = 2 + 2 * FA_ADMM_BLOCKS
 
@@ -83,6 +84,16 @@ SIGNATURES = {
     "fa_buff_accum_raw_f64": (_i, [_p, _p, _i, _sz, _p]),
     "fa_buff_flush_mean_f64": (_i, [_p, _p, _i, _sz, _p]),
     "fa_fill_f64": (_i, [_p, _d, _sz, _p]),
+    "fa_half_round_scalar": (_f, [_d, _i]),
+    "fa_half_reduce_opt": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _i, _p]),
+    "fa_half_reduce_step": (_i, [_p, _p, _i, _p, _p, _sz, _i, _p]),
+    "fa_half_server_opt_step": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _i, _p]),
+    "fa_half_apply_step": (_i, [_p, _p, _sz, _i, _p]),
+    "fa_half_mean": (_i, [_p, _i, _p, _sz, _i, _p]),
+    "fa_half_async_mix": (_i, [_p, _d, _i, _i, _p, _p, _sz, _i, _p]),
+    "fa_half_buff_accum": (_i, [_p, _d, _i, _p, _p, _i, _i, _sz, _i, _p]),
+    "fa_half_buff_accum_raw": (_i, [_p, _p, _i, _sz, _i, _p]),
+    "fa_half_buff_flush_mean": (_i, [_p, _p, _i, _sz, _i, _p]),
     "fa_synth_fill": (_i, [_p, _p, _sz, _u64, _u64, _f, _p]),
     "fa_pack_host": (_i, [_p, _p, _p, _p, _i, _i]),
     "fa_pack_host_window": (_i, [_p, _p, _p, _p, _i, _sz, _sz, _i]),

@@ -18,7 +18,7 @@ from typing import Any, Dict, Optional, OrderedDict, Union
 
 import torch
 
-from .. import ops
+from .. import half_ops, ops
 from ..layout import MEAN_F32, MEAN_F64, MEAN_I32, MEAN_I64, STEP, STEP_F64, Layout
 from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import (BaseAggregator, DeviceStateMixin, cfg_get, cfg_require,
@@ -50,6 +50,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         self.client_step = {}
         self.step: Dict[str, torch.Tensor] = {}
         self.device = resolve_device(self.aggregator_configs)
+        self._ops = ops          # the flat kernels; the rounding ones once a 16-bit layout is known
         self._layout: Optional[Layout] = None
         self._flats: Optional[Dict[str, torch.Tensor]] = None
         self._slab: Optional[ClientSlab] = None
@@ -103,6 +104,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
                 self._layout.view(self._flats, n).copy_(t.detach())
         self._slab = ClientSlab(self._layout, self.device, slots=2)
         self._slab.reserve(1)
+        self._ops = half_ops.for_layout(self._layout, ops)
 
     def _warn_unrecorded_download(self, client_id) -> None:
         if getattr(self, "_download_warning_issued", False) or self.logger is None:
@@ -156,13 +158,13 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         """Enqueue the kernels of one arrival staged in row 0 of the slab."""
         n_step = self._layout.count[STEP]
         if n_step:
-            ops.async_mix(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t,
+            self._ops.async_mix(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t,
                           self._flats["f32"],
                           gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                           sub_form=bool(self.optimize_memory), n=n_step)
         n64 = self._layout.count[STEP_F64]
         if n64:
-            ops.async_mix(self._slab.row_view(0, self._layout.seg_byte[STEP_F64], n64, torch.float64),
+            self._ops.async_mix(self._slab.row_view(0, self._layout.seg_byte[STEP_F64], n64, torch.float64),
                           alpha_t, self._flats["f64"],
                           gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                           sub_form=bool(self.optimize_memory), n=n64)
@@ -179,7 +181,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         path, so the same bits.  Returns None when it does not apply."""
         lay = self._layout
         n_step = lay.count[STEP]
-        if n_step < self.PIPELINE_MIN_ELEMENTS or lay.n_f64 or any(
+        if n_step < self.PIPELINE_MIN_ELEMENTS or lay.n_f64 or lay.half_dtype is not None or any(
                 not isinstance(t, torch.Tensor) or t.is_cuda for t in local_model.values()):
             return None
         out_f32 = self._dl.lease(torch.float32, lay.n_f32)
@@ -201,7 +203,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
             if upto <= done:
                 return
             compute.wait_event(landed)
-            ops.async_mix(row[done:], alpha_t, g[done:], gradient_based=gradient_based,
+            self._ops.async_mix(row[done:], alpha_t, g[done:], gradient_based=gradient_based,
                           sub_form=bool(self.optimize_memory), n=upto - done)
             mixed = torch.cuda.Event()
             mixed.record(compute)
@@ -264,13 +266,13 @@ class FedBuffAggregator(FedAsyncAggregator):
         n_step = lay.count[STEP]
         g, st = self._flats, self._step_flats
         if n_step:
-            ops.buff_accum(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t, g["f32"],
+            self._ops.buff_accum(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t, g["f32"],
                            st["f32"], first,
                            gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                            flush=flush, n=n_step)
         n64 = lay.count[STEP_F64]
         if n64:
-            ops.buff_accum(self._slab.row_view(0, lay.seg_byte[STEP_F64], n64, torch.float64), alpha_t,
+            self._ops.buff_accum(self._slab.row_view(0, lay.seg_byte[STEP_F64], n64, torch.float64), alpha_t,
                            g["f64"], st["f64"], first,
                            gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                            flush=flush, n=n64)
@@ -282,10 +284,10 @@ class FedBuffAggregator(FedAsyncAggregator):
             cnt = lay.count[cls]
             if not cnt:
                 continue
-            ops.buff_accum_raw(self._slab.row_view(0, lay.seg_byte[cls], cnt, dtype),
+            self._ops.buff_accum_raw(self._slab.row_view(0, lay.seg_byte[cls], cnt, dtype),
                                st[key][lo:lo + cnt], first, n=cnt)
             if flush:
-                ops.buff_flush_mean(g[key][lo:lo + cnt], st[key][lo:lo + cnt], self.K, n=cnt)
+                self._ops.buff_flush_mean(g[key][lo:lo + cnt], st[key][lo:lo + cnt], self.K, n=cnt)
 
     # -- aggregate: fedbuff_aggregator.py:25-105 with compute_steps :107-158 ------------------------
     def aggregate(self, client_id: Union[str, int], local_model: Union[Dict, OrderedDict],
@@ -321,7 +323,7 @@ class FedBuffAggregator(FedAsyncAggregator):
         back while the arrival is still being uploaded: the transfers share the full-duplex
         link instead of queueing.  None when no pinned lease is to be had."""
         lay = self._layout
-        if lay.n_f32 < self.PIPELINE_MIN_ELEMENTS or lay.n_f64:
+        if lay.n_f32 < self.PIPELINE_MIN_ELEMENTS or lay.n_f64 or lay.half_dtype is not None:
             return None
         host = {}
         for key, dtype, n in (("f32", torch.float32, lay.n_f32), ("i64", torch.int64, lay.count[MEAN_I64]),

@@ -82,6 +82,11 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
             init = dict(first_model)
         self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
                               self.named_parameters)
+        if self._layout.half_dtype is not None:
+            self._layout = None
+            raise NotImplementedError(
+                "FedCompass / FedQueue on bfloat16 / float16 state dicts are not supported by the MI355X "
+                "aggregation kernels (fp32 and fp64 are); there is no CPU fallback")
         self._flats = self._layout.alloc_state(self.device)
         with torch.no_grad():
             for n, t in init.items():

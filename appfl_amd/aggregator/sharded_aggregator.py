@@ -128,6 +128,9 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         segment, the small entries whole, and the gathered copy of the weighted segment (built
         locally: every rank sees the same initial values)."""
         full = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()], self.named_parameters)
+        if full.half_dtype is not None:
+            raise NotImplementedError("bfloat16 / float16 state dicts are not supported by the sharded "
+                                      "(multi-GPU) aggregator; there is no CPU fallback")
         smap = ShardMap(full.count[STEP], self.world, self.rank, self._pieces)
         lay = WindowedLayout(full, smap.windows(), smap.L)
         flats = lay.alloc_state(self.device)
@@ -418,6 +421,11 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
                 init = {n: model_state[n] for n in first if n in model_state}
             else:
                 init = dict(first)
+            for n, t in init.items():
+                if t.dtype not in _DTYPE_NAMES:
+                    raise NotImplementedError(
+                        f"{n}: {t.dtype} entries are not supported by the sharded (multi-GPU) aggregator "
+                        "(fp32, fp64, int64 and int32 are); there is no CPU fallback")
             spec[0] = [(n, tuple(t.shape), _DTYPE_NAMES[t.dtype]) for n, t in init.items()]
         if self.world > 1:
             src = dist.get_global_rank(self.group, 0) if self.group is not None else 0

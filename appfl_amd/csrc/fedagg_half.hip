@@ -1,0 +1,564 @@
+// fedagg_half.hip -- the aggregation kernels for bfloat16 / float16 state-dict entries.
+//
+// The reference's float path takes any float tensor (misc/memory_utils.py:112-131).  On 16-bit
+// float tensors PyTorch's CPU kernels evaluate every single tensor operation in fp32 and round
+// its result to the 16-bit type (nearest, ties to even); nothing is fused across operations.  A
+// Python scalar that multiplies or divides such a tensor enters as its fp32 value; one that is
+// added (tau, tau**2) or passed as `alpha=` of add_ / sub_ is first rounded to the tensor's type.
+//
+// Here the values travel in fp32 CARRIERS: device buffers of floats that only ever hold values
+// representable in the 16-bit type (the widening on upload and the narrowing on download are
+// exact).  Every kernel below is the fp32 formula of the entry point of the same name with each
+// operation's result passed through round<HALF>() -- the hardware's round-to-nearest-even
+// conversion to the 16-bit type and back -- so results equal the reference's bit for bit.
+// Carriers cost twice the bytes a 16-bit row format would; these are plain streaming kernels
+// (128-bit loads where the buffers allow it, eight client loads in flight), not the tuned fp32 path.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/appfl_amd.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 1 << 20;
+constexpr int kAhead = 8;   // client loads in flight per element / vector
+
+// fp32 -> 16-bit type (round to nearest even) -> fp32.  The empty asm makes the fp32 value
+// opaque to the compiler, so that the conversion stays a conversion of its own: left alone, the
+// compiler merges a multiply and the narrowing that follows it into one mixed-precision
+// instruction (v_fma_mixlo_f16), whose results were measured to differ from multiply-then-convert
+// in the last place of about 2 % of the products.
+template <int HALF>
+__device__ __forceinline__ float rnd(float x) {
+    __asm__("" : "+v"(x));
+    if constexpr (HALF == FA_HALF_BF16) {
+        return static_cast<float>(static_cast<__bf16>(x));
+    } else {
+        return static_cast<float>(static_cast<_Float16>(x));
+    }
+}
+
+template <int HALF>
+float rnd_host(float x) {
+    if (HALF == FA_HALF_BF16) {
+        uint32_t u;
+        memcpy(&u, &x, 4);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return x;   // NaN
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        float r;
+        memcpy(&r, &u, 4);
+        return r;
+    }
+    return static_cast<float>(static_cast<_Float16>(x));
+}
+
+float rnd_host(float x, int half) { return half == FA_HALF_BF16 ? rnd_host<FA_HALF_BF16>(x) : rnd_host<FA_HALF_F16>(x); }
+
+struct HyperH {
+    float lr, b1, omb1, b2, omb2, tau;   // tau already rounded to the 16-bit type (it is ADDED)
+};
+
+template <int VEC>
+struct PackH {
+    float e[VEC];
+};
+
+template <int VEC, bool NT>
+__device__ __forceinline__ PackH<VEC> load_h(const float* p, size_t i) {
+    PackH<VEC> r;
+    if constexpr (VEC == 4) {
+        const f4* q = reinterpret_cast<const f4*>(p) + i;
+        f4 t = NT ? __builtin_nontemporal_load(q) : *q;
+        r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
+    } else {
+        r.e[0] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+    }
+    return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_h(float* p, size_t i, const PackH<VEC>& r) {
+    if constexpr (VEC == 4) {
+        f4 t;
+        t.x = r.e[0]; t.y = r.e[1]; t.z = r.e[2]; t.w = r.e[3];
+        reinterpret_cast<f4*>(p)[i] = t;
+    } else {
+        p[i] = r.e[0];
+    }
+}
+
+__device__ __forceinline__ float sign_h(float d) {
+    return static_cast<float>(static_cast<int>(0.0f < d) - static_cast<int>(d < 0.0f));
+}
+
+// fedavgm_aggregator.py:48-61, fedadam_aggregator.py:60-99, fedyogi_aggregator.py:60-97,
+// fedadagrad_aggregator.py:59-91, one rounding per tensor operation.
+template <int OPT, int HALF>
+__device__ __forceinline__ float optimizer_step_h(float step, float& m, float& v, const HyperH& h) {
+    if (OPT == FA_OPT_NONE) return step;
+    if (OPT == FA_OPT_AVGM) {
+        float mt = rnd<HALF>(v * h.b1);
+        v = rnd<HALF>(mt + step);
+        return v;
+    }
+    float mt = rnd<HALF>(m * h.b1);
+    float st = rnd<HALF>(step * h.omb1);
+    m = rnd<HALF>(mt + st);
+    float s2 = rnd<HALF>(step * step);
+    if (OPT == FA_OPT_ADAM) {
+        float vt = rnd<HALF>(v * h.b2);
+        float sq = rnd<HALF>(s2 * h.omb2);
+        v = rnd<HALF>(vt + sq);
+    } else if (OPT == FA_OPT_YOGI) {
+        float sg = sign_h(rnd<HALF>(v - s2));
+        float yu = rnd<HALF>(s2 * sg);
+        float ys = rnd<HALF>(yu * h.omb2);
+        v = rnd<HALF>(v - ys);
+    } else {
+        v = rnd<HALF>(v + s2);
+    }
+    float num = rnd<HALF>(h.lr * m);
+    float rt = rnd<HALF>(sqrtf(v));
+    float den = rnd<HALF>(rt + h.tau);
+    return rnd<HALF>(num / den);
+}
+
+struct ReduceHArgs {
+    const float* x[FA_KCHUNK];
+    float w[FA_KCHUNK];
+    float* g;
+    const float* g_ro;
+    float* m;
+    float* v;
+    const float* step_in;
+    float* step_out;
+    size_t n;   // elements of width VEC
+    int K, last, apply;
+    HyperH h;
+};
+
+template <int OPT, int HALF, int VEC>
+__global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs a) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.n; i += stride) {
+        const PackH<VEC> g = load_h<VEC, false>(a.apply ? a.g : a.g_ro, i);
+        PackH<VEC> s;
+        if (a.step_in) {
+            s = load_h<VEC, false>(a.step_in, i);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s.e[e] = 0.0f;
+        }
+        int k = 0;
+        for (; k + kAhead <= a.K; k += kAhead) {
+            PackH<VEC> x[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) x[u] = load_h<VEC, true>(a.x[k + u], i);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const float w = a.w[k + u];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float d = rnd<HALF>(x[u].e[e] - g.e[e]);
+                    float wd = rnd<HALF>(d * w);
+                    s.e[e] = rnd<HALF>(s.e[e] + wd);
+                }
+            }
+        }
+        for (; k < a.K; ++k) {
+            const PackH<VEC> x = load_h<VEC, true>(a.x[k], i);
+            const float w = a.w[k];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float d = rnd<HALF>(x.e[e] - g.e[e]);
+                float wd = rnd<HALF>(d * w);
+                s.e[e] = rnd<HALF>(s.e[e] + wd);
+            }
+        }
+        if (!a.last) {
+            store_h<VEC>(a.step_out, i, s);
+            continue;
+        }
+        if (OPT != FA_OPT_NONE) {
+            PackH<VEC> v = load_h<VEC, false>(a.v, i);
+            PackH<VEC> m;
+            if (OPT != FA_OPT_AVGM) {
+                m = load_h<VEC, false>(a.m, i);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) m.e[e] = 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s.e[e] = optimizer_step_h<OPT, HALF>(s.e[e], m.e[e], v.e[e], a.h);
+            store_h<VEC>(a.v, i, v);
+            if (OPT != FA_OPT_AVGM) store_h<VEC>(a.m, i, m);
+        }
+        if (a.step_out) store_h<VEC>(a.step_out, i, s);
+        if (a.apply) {
+            PackH<VEC> r;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r.e[e] = rnd<HALF>(g.e[e] + s.e[e]);
+            store_h<VEC>(a.g, i, r);
+        }
+    }
+}
+
+template <int OPT, int HALF>
+__global__ __launch_bounds__(kThreads) void opt_step_half_kernel(float* step, float* m, float* v, HyperH h, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        float vv = v[i];
+        float mm = (OPT != FA_OPT_AVGM) ? m[i] : 0.0f;
+        step[i] = optimizer_step_h<OPT, HALF>(step[i], mm, vv, h);
+        v[i] = vv;
+        if (OPT != FA_OPT_AVGM) m[i] = mm;
+    }
+}
+
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void apply_half_kernel(float* g, const float* step, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride)
+        g[i] = rnd<HALF>(g[i] + step[i]);
+}
+
+struct MeanHArgs {
+    const float* x[FA_KCHUNK];
+    float* g;
+    const float* sum_in;
+    size_t n;
+    int K, last;
+    float Kall;
+};
+
+// fedavg_aggregator.py:285-295: param_sum.add_(model[name]) per client, then div_(K).
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void mean_half_kernel(const MeanHArgs a) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.n; i += stride) {
+        float s = a.sum_in ? a.sum_in[i] : 0.0f;
+        for (int k = 0; k < a.K; ++k) s = rnd<HALF>(s + __builtin_nontemporal_load(a.x[k] + i));
+        a.g[i] = a.last ? rnd<HALF>(s / a.Kall) : s;
+    }
+}
+
+// MODE 0: model-based a*(x - g); 1: gradient-based "0 - a*x" (zeros.sub_(x, alpha=a));
+// 2: gradient-based "a * (-x)"  (fedasync_aggregator.py:243-264).
+template <int MODE, int HALF>
+__device__ __forceinline__ float async_step_h(float x, float g, float alpha) {
+    if (MODE == 0) {
+        float d = rnd<HALF>(x - g);
+        return rnd<HALF>(alpha * d);
+    }
+    if (MODE == 1) {
+        float ax = rnd<HALF>(alpha * x);
+        return 0.0f - ax;
+    }
+    float nx = -x;
+    return rnd<HALF>(alpha * nx);
+}
+
+template <int MODE, int HALF>
+__global__ __launch_bounds__(kThreads) void async_mix_half_kernel(const float* x, float alpha, float* g, float* step_out, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        const float gv = g[i];
+        const float s = async_step_h<MODE, HALF>(__builtin_nontemporal_load(x + i), gv, alpha);
+        if (step_out) step_out[i] = s;
+        g[i] = rnd<HALF>(gv + s);
+    }
+}
+
+template <int MODE, int HALF>
+__global__ __launch_bounds__(kThreads) void buff_accum_half_kernel(const float* x, float alpha, float* g, float* step, int first, int flush, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        const float gv = g[i];
+        float s = first ? 0.0f : step[i];
+        const float d = async_step_h<MODE, HALF>(__builtin_nontemporal_load(x + i), gv, alpha);
+        s = rnd<HALF>(s + d);
+        step[i] = s;
+        if (flush) g[i] = rnd<HALF>(gv + s);
+    }
+}
+
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void accum_raw_half_kernel(const float* x, float* step, int first, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        const float s = first ? 0.0f : step[i];
+        step[i] = rnd<HALF>(s + x[i]);
+    }
+}
+
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void flush_mean_half_kernel(float* g, const float* step, float kf, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride)
+        g[i] = rnd<HALF>(step[i] / kf);
+}
+
+inline hipStream_t as_stream(fa_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FA_OK : FA_ERR_HIP - static_cast<int>(e);
+}
+inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool known(int half) { return half == FA_HALF_BF16 || half == FA_HALF_F16; }
+inline unsigned grid_for(size_t n) {
+    size_t b = (n + kThreads - 1) / kThreads;
+    return static_cast<unsigned>(b < 1 ? 1 : (b > static_cast<size_t>(kMaxBlocks) ? kMaxBlocks : b));
+}
+
+HyperH make_hyper_h(double lr, double beta1, double beta2, double tau, int half) {
+    return HyperH{static_cast<float>(lr), static_cast<float>(beta1), static_cast<float>(1.0 - beta1),
+                  static_cast<float>(beta2), static_cast<float>(1.0 - beta2),
+                  rnd_host(static_cast<float>(tau), half)};
+}
+
+template <int HALF, int VEC>
+void launch_reduce_half(int opt, const ReduceHArgs& a, hipStream_t st) {
+    const dim3 grid(grid_for(a.n)), block(kThreads);
+    switch (opt) {
+        case FA_OPT_NONE: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_NONE, HALF, VEC>), grid, block, 0, st, a); break;
+        case FA_OPT_AVGM: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_AVGM, HALF, VEC>), grid, block, 0, st, a); break;
+        case FA_OPT_ADAM: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_ADAM, HALF, VEC>), grid, block, 0, st, a); break;
+        case FA_OPT_YOGI: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_YOGI, HALF, VEC>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_ADAGRAD, HALF, VEC>), grid, block, 0, st, a); break;
+    }
+}
+
+int reduce_half(const float* const* x, const double* w, int K, float* g, const float* g_ro, float* m, float* v,
+                size_t n, int opt, const HyperH& h, float* step_out, float* step_ws, int apply, int half,
+                hipStream_t st) {
+    if (!x || !w || K <= 0 || !known(half)) return FA_ERR_INVALID;
+    if (apply ? !g : (!g_ro || !step_out)) return FA_ERR_INVALID;
+    if (opt < FA_OPT_NONE || opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
+    if (opt != FA_OPT_NONE && !v) return FA_ERR_INVALID;
+    if (opt >= FA_OPT_ADAM && !m) return FA_ERR_INVALID;
+    if (K > FA_KCHUNK && !step_out && !step_ws) return FA_ERR_WORKSPACE;
+    const void* ptrs[] = {g, g_ro, m, v, step_out, step_ws};
+    bool wide = true;
+    for (const void* p : ptrs) {
+        if (p && !aligned4(p)) return FA_ERR_ALIGN;
+        wide = wide && (!p || aligned16(p));
+    }
+    for (int k = 0; k < K; ++k) {
+        if (!x[k]) return FA_ERR_INVALID;
+        if (!aligned4(x[k])) return FA_ERR_ALIGN;
+        wide = wide && aligned16(x[k]);
+    }
+    if (n == 0) return FA_OK;
+    const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
+    float* carry = step_out ? step_out : step_ws;
+    // 128-bit body over the leading whole vectors when every buffer allows it, scalar kernel over the rest
+    const size_t body = wide ? n / 4 * 4 : 0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        ReduceHArgs a;
+        memset(&a, 0, sizeof(a));
+        const int k0 = ch * FA_KCHUNK;
+        a.K = (K - k0 < FA_KCHUNK) ? K - k0 : FA_KCHUNK;
+        a.last = (ch == chunks - 1);
+        a.apply = apply;
+        a.h = h;
+        const int o = a.last ? opt : FA_OPT_NONE;
+        for (int part = 0; part < 2; ++part) {
+            const size_t lo = part ? body : 0, cnt = part ? n - body : body;
+            if (cnt == 0) continue;
+            for (int k = 0; k < a.K; ++k) {
+                a.x[k] = x[k0 + k] + lo;
+                a.w[k] = static_cast<float>(w[k0 + k]);
+            }
+            a.g = g ? g + lo : nullptr;
+            a.g_ro = g_ro ? g_ro + lo : nullptr;
+            a.m = m ? m + lo : nullptr;
+            a.v = v ? v + lo : nullptr;
+            a.step_in = (ch == 0) ? nullptr : carry + lo;
+            float* so = a.last ? step_out : carry;
+            a.step_out = so ? so + lo : nullptr;
+            if (part == 0) {
+                a.n = cnt / 4;
+                if (half == FA_HALF_BF16) launch_reduce_half<FA_HALF_BF16, 4>(o, a, st); else launch_reduce_half<FA_HALF_F16, 4>(o, a, st);
+            } else {
+                a.n = cnt;
+                if (half == FA_HALF_BF16) launch_reduce_half<FA_HALF_BF16, 1>(o, a, st); else launch_reduce_half<FA_HALF_F16, 1>(o, a, st);
+            }
+            int rc = launch_status();
+            if (rc != FA_OK) return rc;
+        }
+    }
+    return FA_OK;
+}
+
+template <int HALF>
+int async_half(const float* x, float alpha, int gradient_based, int sub_form, float* g, float* step_out,
+               size_t n, hipStream_t st) {
+    const dim3 grid(grid_for(n)), block(kThreads);
+    if (!gradient_based)
+        hipLaunchKernelGGL((async_mix_half_kernel<0, HALF>), grid, block, 0, st, x, alpha, g, step_out, n);
+    else if (sub_form)
+        hipLaunchKernelGGL((async_mix_half_kernel<1, HALF>), grid, block, 0, st, x, alpha, g, step_out, n);
+    else
+        hipLaunchKernelGGL((async_mix_half_kernel<2, HALF>), grid, block, 0, st, x, alpha, g, step_out, n);
+    return launch_status();
+}
+
+template <int HALF>
+int buff_half(const float* x, float alpha, int gradient_based, float* g, float* step, int first, int flush,
+              size_t n, hipStream_t st) {
+    const dim3 grid(grid_for(n)), block(kThreads);
+    if (gradient_based)
+        hipLaunchKernelGGL((buff_accum_half_kernel<2, HALF>), grid, block, 0, st, x, alpha, g, step, first, flush, n);
+    else
+        hipLaunchKernelGGL((buff_accum_half_kernel<0, HALF>), grid, block, 0, st, x, alpha, g, step, first, flush, n);
+    return launch_status();
+}
+
+template <int HALF>
+int opt_step_half(float* step, float* m, float* v, size_t n, int opt, const HyperH& h, hipStream_t st) {
+    const dim3 grid(grid_for(n)), block(kThreads);
+    switch (opt) {
+        case FA_OPT_AVGM: hipLaunchKernelGGL((opt_step_half_kernel<FA_OPT_AVGM, HALF>), grid, block, 0, st, step, m, v, h, n); break;
+        case FA_OPT_ADAM: hipLaunchKernelGGL((opt_step_half_kernel<FA_OPT_ADAM, HALF>), grid, block, 0, st, step, m, v, h, n); break;
+        case FA_OPT_YOGI: hipLaunchKernelGGL((opt_step_half_kernel<FA_OPT_YOGI, HALF>), grid, block, 0, st, step, m, v, h, n); break;
+        default: hipLaunchKernelGGL((opt_step_half_kernel<FA_OPT_ADAGRAD, HALF>), grid, block, 0, st, step, m, v, h, n); break;
+    }
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+float fa_half_round_scalar(double x, int half) {
+    return known(half) ? rnd_host(static_cast<float>(x), half) : static_cast<float>(x);
+}
+
+int fa_half_reduce_opt(const float* const* x, const double* w, int K, float* g, float* m, float* v, size_t n,
+                       int opt, double lr, double beta1, double beta2, double tau, float* step_out,
+                       float* step_ws, int half, fa_stream_t stream) {
+    return reduce_half(x, w, K, g, nullptr, m, v, n, opt, make_hyper_h(lr, beta1, beta2, tau, half), step_out,
+                       step_ws, 1, half, as_stream(stream));
+}
+
+int fa_half_reduce_step(const float* const* x, const double* w, int K, const float* g, float* step_out,
+                        size_t n, int half, fa_stream_t stream) {
+    return reduce_half(x, w, K, nullptr, g, nullptr, nullptr, n, FA_OPT_NONE, make_hyper_h(0, 0, 0, 0, half),
+                       step_out, nullptr, 0, half, as_stream(stream));
+}
+
+int fa_half_server_opt_step(float* step, float* m, float* v, size_t n, int opt, double lr, double beta1,
+                            double beta2, double tau, int half, fa_stream_t stream) {
+    if (!known(half)) return FA_ERR_INVALID;
+    if (opt == FA_OPT_NONE) return FA_OK;
+    if (opt < FA_OPT_NONE || opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
+    if (!step || !v || (opt >= FA_OPT_ADAM && !m)) return FA_ERR_INVALID;
+    if (!aligned4(step) || !aligned4(v) || (m && !aligned4(m))) return FA_ERR_ALIGN;
+    if (n == 0) return FA_OK;
+    const HyperH h = make_hyper_h(lr, beta1, beta2, tau, half);
+    return half == FA_HALF_BF16 ? opt_step_half<FA_HALF_BF16>(step, m, v, n, opt, h, as_stream(stream))
+                                : opt_step_half<FA_HALF_F16>(step, m, v, n, opt, h, as_stream(stream));
+}
+
+int fa_half_apply_step(float* g, const float* step, size_t n, int half, fa_stream_t stream) {
+    if (!g || !step || !known(half)) return FA_ERR_INVALID;
+    if (!aligned4(g) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (n == 0) return FA_OK;
+    const dim3 grid(grid_for(n)), block(kThreads);
+    if (half == FA_HALF_BF16)
+        hipLaunchKernelGGL((apply_half_kernel<FA_HALF_BF16>), grid, block, 0, as_stream(stream), g, step, n);
+    else
+        hipLaunchKernelGGL((apply_half_kernel<FA_HALF_F16>), grid, block, 0, as_stream(stream), g, step, n);
+    return launch_status();
+}
+
+int fa_half_mean(const float* const* x, int K, float* g, size_t n, int half, fa_stream_t stream) {
+    if (!x || !g || K <= 0 || !known(half)) return FA_ERR_INVALID;
+    if (!aligned4(g)) return FA_ERR_ALIGN;
+    for (int k = 0; k < K; ++k) {
+        if (!x[k]) return FA_ERR_INVALID;
+        if (!aligned4(x[k])) return FA_ERR_ALIGN;
+    }
+    if (n == 0) return FA_OK;
+    const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
+    for (int ch = 0; ch < chunks; ++ch) {
+        MeanHArgs a;
+        memset(&a, 0, sizeof(a));
+        const int k0 = ch * FA_KCHUNK;
+        a.K = (K - k0 < FA_KCHUNK) ? K - k0 : FA_KCHUNK;
+        for (int k = 0; k < a.K; ++k) a.x[k] = x[k0 + k];
+        a.g = g;
+        a.sum_in = (ch == 0) ? nullptr : g;
+        a.n = n;
+        a.last = (ch == chunks - 1);
+        a.Kall = static_cast<float>(K);
+        const dim3 grid(grid_for(n)), block(kThreads);
+        if (half == FA_HALF_BF16)
+            hipLaunchKernelGGL((mean_half_kernel<FA_HALF_BF16>), grid, block, 0, as_stream(stream), a);
+        else
+            hipLaunchKernelGGL((mean_half_kernel<FA_HALF_F16>), grid, block, 0, as_stream(stream), a);
+        int rc = launch_status();
+        if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
+}
+
+int fa_half_async_mix(const float* x, double alpha_t, int gradient_based, int sub_form, float* g,
+                      float* step_out, size_t n, int half, fa_stream_t stream) {
+    if (!x || !g || !known(half)) return FA_ERR_INVALID;
+    if (!aligned4(x) || !aligned4(g) || (step_out && !aligned4(step_out))) return FA_ERR_ALIGN;
+    if (n == 0) return FA_OK;
+    // sub_form = the reference's optimize_memory branch, which passes alpha_t as `alpha=` of
+    // add_ / sub_ (fedasync_aggregator.py:246-258): PyTorch casts that scalar to the tensor's type
+    float alpha = static_cast<float>(alpha_t);
+    if (sub_form) alpha = rnd_host(alpha, half);
+    return half == FA_HALF_BF16
+               ? async_half<FA_HALF_BF16>(x, alpha, gradient_based, sub_form, g, step_out, n, as_stream(stream))
+               : async_half<FA_HALF_F16>(x, alpha, gradient_based, sub_form, g, step_out, n, as_stream(stream));
+}
+
+int fa_half_buff_accum(const float* x, double alpha_t, int gradient_based, float* g, float* step, int first,
+                       int flush, size_t n, int half, fa_stream_t stream) {
+    if (!x || !g || !step || !known(half)) return FA_ERR_INVALID;
+    if (!aligned4(x) || !aligned4(g) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (n == 0) return FA_OK;
+    const float alpha = static_cast<float>(alpha_t);
+    return half == FA_HALF_BF16
+               ? buff_half<FA_HALF_BF16>(x, alpha, gradient_based, g, step, first, flush, n, as_stream(stream))
+               : buff_half<FA_HALF_F16>(x, alpha, gradient_based, g, step, first, flush, n, as_stream(stream));
+}
+
+int fa_half_buff_accum_raw(const float* x, float* step, int first, size_t n, int half, fa_stream_t stream) {
+    if (!x || !step || !known(half)) return FA_ERR_INVALID;
+    if (!aligned4(x) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (n == 0) return FA_OK;
+    const dim3 grid(grid_for(n)), block(kThreads);
+    if (half == FA_HALF_BF16)
+        hipLaunchKernelGGL((accum_raw_half_kernel<FA_HALF_BF16>), grid, block, 0, as_stream(stream), x, step, first, n);
+    else
+        hipLaunchKernelGGL((accum_raw_half_kernel<FA_HALF_F16>), grid, block, 0, as_stream(stream), x, step, first, n);
+    return launch_status();
+}
+
+int fa_half_buff_flush_mean(float* g, const float* step, int K, size_t n, int half, fa_stream_t stream) {
+    if (!g || !step || K <= 0 || !known(half)) return FA_ERR_INVALID;
+    if (!aligned4(g) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (n == 0) return FA_OK;
+    const dim3 grid(grid_for(n)), block(kThreads);
+    if (half == FA_HALF_BF16)
+        hipLaunchKernelGGL((flush_mean_half_kernel<FA_HALF_BF16>), grid, block, 0, as_stream(stream), g, step,
+                           static_cast<float>(K), n);
+    else
+        hipLaunchKernelGGL((flush_mean_half_kernel<FA_HALF_F16>), grid, block, 0, as_stream(stream), g, step,
+                           static_cast<float>(K), n);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -9,6 +9,13 @@ The aggregation kernels work on flat vectors, one per arithmetic class:
 
 (classification: algorithm/aggregator/fedavg_aggregator.py:333-340 of the reference.)
 
+bfloat16 / float16 entries take the two fp32 classes: on the device they ride in fp32 CARRIERS
+(floats that only hold values of the 16-bit type; widening and narrowing are exact) and the
+kernels of :mod:`appfl_amd.half_ops` round every operation to the 16-bit type.  An entry's
+`dtype` is then the carrier's (float32), its `model_dtype` the 16-bit type the caller sees.  All
+entries of the two fp32 classes must share one type: a state dict that mixes fp32 with 16-bit
+tensors (or the two 16-bit types) is refused.
+
 A client's state dict is packed into one ROW of bytes with the segments in that order::
 
     [ step fp32 ... | mean fp32 ... | pad to 16 | step fp64 ... | mean fp64 ... | int64 ... | int32 ... | pad to 256 ]
@@ -33,6 +40,7 @@ _ITEMSIZE = {STEP: 4, MEAN_F32: 4, STEP_F64: 8, MEAN_F64: 8, MEAN_I64: 8, MEAN_I
 _DTYPE = {STEP: torch.float32, MEAN_F32: torch.float32, STEP_F64: torch.float64,
           MEAN_F64: torch.float64, MEAN_I64: torch.int64, MEAN_I32: torch.int32}
 ROW_ALIGN = 256
+HALF_DTYPES = (torch.bfloat16, torch.float16)
 
 
 def _round_up(x: int, a: int) -> int:
@@ -50,6 +58,11 @@ class Entry:
     byte_offset: int   # byte offset inside a row
     src_offset: int = 0    # first element of the client's tensor this entry covers
     full_numel: int = -1   # elements of the client's whole tensor (-1: numel, the entry is whole)
+    model_dtype: Optional[torch.dtype] = None   # the caller's dtype when it is not `dtype` (16-bit floats)
+
+    @property
+    def caller_dtype(self) -> torch.dtype:
+        return self.model_dtype or self.dtype
 
 
 def classify(dtype: torch.dtype, is_parameter: bool) -> str:
@@ -60,10 +73,10 @@ def classify(dtype: torch.dtype, is_parameter: bool) -> str:
         return MEAN_I32
     if dtype == torch.float64:
         return STEP_F64 if is_parameter else MEAN_F64
-    if dtype != torch.float32:
+    if dtype not in (torch.float32,) + HALF_DTYPES:
         raise NotImplementedError(
             f"state-dict entries of dtype {dtype} are not supported by the MI355X aggregation "
-            "kernels (fp32, fp64, int64 and int32 are); there is no CPU fallback")
+            "kernels (fp32, bf16, fp16, fp64, int64 and int32 are); there is no CPU fallback")
     return STEP if is_parameter else MEAN_F32
 
 
@@ -73,9 +86,21 @@ class Layout:
     def __init__(self, names_shapes_dtypes: Sequence[Tuple[str, Tuple[int, ...], torch.dtype]],
                  named_parameters: Optional[Set[str]] = None):
         order = {c: [] for c in CLASSES}
+        kinds = set()
         for name, shape, dtype in names_shapes_dtypes:
             is_param = named_parameters is None or name in named_parameters
-            order[classify(dtype, is_param)].append((name, tuple(shape), dtype))
+            cls = classify(dtype, is_param)
+            order[cls].append((name, tuple(shape), dtype))
+            if cls in (STEP, MEAN_F32):
+                kinds.add(dtype)
+        if len(kinds) > 1:
+            raise NotImplementedError(
+                f"a state dict that mixes {sorted(str(k) for k in kinds)} entries is not supported by "
+                "the MI355X aggregation kernels: fp32, bfloat16 and float16 tensors each need a state "
+                "dict of their own kind (float64 and integer entries may accompany any of them)")
+        kind = next(iter(kinds), torch.float32)
+        # the 16-bit type the fp32-class entries are rounded to (None: they are plain fp32)
+        self.half_dtype: Optional[torch.dtype] = kind if kind in HALF_DTYPES else None
         self.count = {c: sum(_numel(s) for _, s, _ in order[c]) for c in order}
         self.n_f32 = self.count[STEP] + self.count[MEAN_F32]
         self.n_f64 = self.count[STEP_F64] + self.count[MEAN_F64]
@@ -85,8 +110,9 @@ class Layout:
             off = 0
             for name, shape, dtype in order[c]:
                 n = _numel(shape)
-                by_name[name] = Entry(name, shape, dtype, n, c, off,
-                                      self.seg_byte[c] + off * _ITEMSIZE[c])
+                by_name[name] = Entry(name, shape, _DTYPE[c], n, c, off,
+                                      self.seg_byte[c] + off * _ITEMSIZE[c],
+                                      model_dtype=dtype if dtype != _DTYPE[c] else None)
                 off += n
         # global-state (dict) order is the order the names were given in
         self.entries: List[Entry] = [by_name[n] for n, _, _ in names_shapes_dtypes]
@@ -131,14 +157,23 @@ class Layout:
         return e.offset
 
     def view(self, flats: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
+        """The entry's stretch of its flat vector, writable (for a 16-bit entry: the fp32 carrier)."""
         e = self.by_name[name]
         off = self.flat_offset(e)
         return flats[self.flat_key(e.cls)][off:off + e.numel].view(e.shape)
 
+    def export(self, flats: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
+        """The entry as the caller sees it: `view`, narrowed to the 16-bit type (a copy) for a
+        16-bit entry."""
+        t = self.view(flats, name)
+        md = self.by_name[name].model_dtype
+        return t if md is None else t.to(md)
+
     def views(self, flats: Dict[str, torch.Tensor], classes: Optional[Iterable[str]] = None
               ) -> Dict[str, torch.Tensor]:
+        """{name: `export`} of every entry (of the given classes)."""
         keep = None if classes is None else set(classes)
-        return {e.name: self.view(flats, e.name) for e in self.entries
+        return {e.name: self.export(flats, e.name) for e in self.entries
                 if keep is None or e.cls in keep}
 
     def matches(self, state: Dict[str, torch.Tensor]) -> bool:
@@ -147,7 +182,7 @@ class Layout:
             return False
         for e in self.entries:
             t = state.get(e.name)
-            if t is None or tuple(t.shape) != e.shape or t.dtype != e.dtype:
+            if t is None or tuple(t.shape) != e.shape or t.dtype != e.caller_dtype:
                 return False
         return True
 
@@ -168,6 +203,10 @@ class WindowedLayout(Layout):
     def __init__(self, full: Layout, windows: Sequence[Tuple[int, int, int]], storage: int):
         if storage % 4:
             raise ValueError("step storage must be a multiple of 4 elements (16 bytes)")
+        if full.half_dtype is not None:
+            raise NotImplementedError("bfloat16 / float16 state dicts are not supported by the sharded "
+                                      "(multi-GPU) aggregator; there is no CPU fallback")
+        self.half_dtype = None
         self.full = full
         self.count = dict(full.count)
         self.count[STEP] = storage

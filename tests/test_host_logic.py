@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "appfl_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(fa_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|float|const char\*)\s+(fa_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 25
     lib = N.load()
     for name in declared:
@@ -126,7 +126,24 @@ def test_layout_classes_offsets_and_rows():
     nomodel = L.Layout([(n, tuple(t.shape), t.dtype) for n, t in state.items()], None)
     assert nomodel.count[L.MEAN_F32] == 0
     with pytest.raises(NotImplementedError):
-        L.Layout([("h", (3,), torch.float16)], None)
+        L.Layout([("h", (3,), torch.int8)], None)
+    # 16-bit floats ride in fp32 carriers: same offsets as the fp32 layout, the caller's dtype kept
+    # beside the carrier's; a state dict that mixes float kinds is refused
+    half = L.Layout([(n, tuple(t.shape), torch.bfloat16 if t.dtype == torch.float32 else t.dtype)
+                     for n, t in state.items()], named)
+    assert half.half_dtype == torch.bfloat16 and lay.half_dtype is None
+    assert [(e.name, e.cls, e.byte_offset) for e in half.entries] == [(e.name, e.cls, e.byte_offset) for e in lay.entries]
+    e = half.by_name["fc.weight"]
+    assert e.dtype == torch.float32 and e.model_dtype == torch.bfloat16 and e.caller_dtype == torch.bfloat16
+    assert half.by_name["bn.num_batches_tracked"].model_dtype is None
+    hv = half.views(flats)
+    assert hv["fc.weight"].dtype == torch.bfloat16 and half.view(flats, "fc.weight").dtype == torch.float32
+    assert half.matches({n: (t.to(torch.bfloat16) if t.dtype == torch.float32 else t) for n, t in state.items()})
+    assert not half.matches(state) and lay.matches(state)
+    for kinds in ((torch.float32, torch.bfloat16), (torch.float16, torch.bfloat16)):
+        with pytest.raises(NotImplementedError):
+            L.Layout([("a", (3,), kinds[0]), ("b", (3,), kinds[1])], None)
+    L.Layout([("a", (3,), torch.float16), ("b", (3,), torch.float64), ("c", (), torch.int64)], None)
 
 
 def test_chunking_rule():
