@@ -94,6 +94,7 @@ SIGNATURES = {
     "fa_half_buff_accum": (_i, [_p, _d, _i, _p, _p, _i, _i, _sz, _i, _p]),
     "fa_half_buff_accum_raw": (_i, [_p, _p, _i, _sz, _i, _p]),
     "fa_half_buff_flush_mean": (_i, [_p, _p, _i, _sz, _i, _p]),
+    "fa_half_fill": (_i, [_p, _d, _sz, _i, _p]),
     "fa_synth_fill": (_i, [_p, _p, _sz, _u64, _u64, _f, _p]),
     "fa_pack_host": (_i, [_p, _p, _p, _p, _i, _i]),
     "fa_pack_host_window": (_i, [_p, _p, _p, _p, _i, _sz, _sz, _i]),

@@ -143,7 +143,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         lay, n_step = self._layout, self._layout.count[STEP]
         if lay.count[MEAN_F32]:
             self._flats["f32"][n_step:lay.n_f32].copy_(
-                self._slab.row_view(0, lay.seg_byte[MEAN_F32], lay.count[MEAN_F32], torch.float32))
+                self._slab.row_view(0, lay.seg_byte[MEAN_F32], lay.count[MEAN_F32], lay.float_dtype))
         if lay.count[MEAN_F64]:
             self._flats["f64"][lay.count[STEP_F64]:lay.n_f64].copy_(
                 self._slab.row_view(0, lay.seg_byte[MEAN_F64], lay.count[MEAN_F64], torch.float64))
@@ -158,7 +158,7 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         """Enqueue the kernels of one arrival staged in row 0 of the slab."""
         n_step = self._layout.count[STEP]
         if n_step:
-            self._ops.async_mix(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t,
+            self._ops.async_mix(self._slab.row_view(0, 0, n_step, self._layout.float_dtype), alpha_t,
                           self._flats["f32"],
                           gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                           sub_form=bool(self.optimize_memory), n=n_step)
@@ -266,7 +266,7 @@ class FedBuffAggregator(FedAsyncAggregator):
         n_step = lay.count[STEP]
         g, st = self._flats, self._step_flats
         if n_step:
-            self._ops.buff_accum(self._slab.row_view(0, 0, n_step, torch.float32), alpha_t, g["f32"],
+            self._ops.buff_accum(self._slab.row_view(0, 0, n_step, lay.float_dtype), alpha_t, g["f32"],
                            st["f32"], first,
                            gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                            flush=flush, n=n_step)
@@ -277,7 +277,7 @@ class FedBuffAggregator(FedAsyncAggregator):
                            gradient_based=cfg_get(self.aggregator_configs, "gradient_based", False),
                            flush=flush, n=n64)
         # entries outside the step are summed raw and flushed as a mean (:146-152, :84-86)
-        for cls, key, dtype, lo in ((MEAN_F32, "f32", torch.float32, n_step),
+        for cls, key, dtype, lo in ((MEAN_F32, "f32", lay.float_dtype, n_step),
                                     (MEAN_F64, "f64", torch.float64, n64),
                                     (MEAN_I64, "i64", torch.int64, 0),
                                     (MEAN_I32, "i32", torch.int32, 0)):

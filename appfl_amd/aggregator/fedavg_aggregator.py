@@ -54,12 +54,6 @@ def _download_flats(lay: Layout, flats: Dict[str, torch.Tensor],
     return out
 
 
-def _narrow(t: torch.Tensor, e) -> torch.Tensor:
-    """A stretch of an fp32 carrier as the 16-bit tensor the caller expects (a copy); anything
-    else unchanged."""
-    return t if e.model_dtype is None else t.to(e.model_dtype)
-
-
 def _native(fn):
     """Marks a compute_steps implementation of this package (a user override lacks the mark and
     switches `aggregate` to the un-fused compute_steps -> apply sequence)."""
@@ -113,7 +107,6 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         # entries of the global state that streamed rounds created outside the flat layout
         # (name -> device tensor, in the order the reference's dict would hold them)
         self._extra_state: Dict[str, torch.Tensor] = {}
-        self._extra_dtype: Dict[str, torch.dtype] = {}   # ... and the 16-bit type of those held in fp32 carriers
         self._dl = HostDownloader()
         self._uploads_pending = False     # `_stage` left the compute stream un-ordered against the uploads
         # clients staged on arrival whose terms of the weighted step are folded already, under
@@ -129,27 +122,18 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
     def global_state(self) -> Optional[Dict[str, torch.Tensor]]:
         """{name: device tensor} views of the flat global state (None before the first round)."""
         if self._layout is None:
-            return self._extra_exported() if self._extra_state else None
+            return dict(self._extra_state) if self._extra_state else None
         out = self._layout.views(self._flats)
-        out.update(self._extra_exported())
-        return out
-
-    def _extra_exported(self, to_cpu: bool = False) -> Dict[str, torch.Tensor]:
-        """The entries streamed rounds created, as the caller sees them (16-bit ones narrowed)."""
-        out = {}
-        for k, v in self._extra_state.items():
-            md = self._extra_dtype.get(k)
-            v = v if md is None else v.to(md)
-            out[k] = v.cpu() if to_cpu else v
+        out.update(self._extra_state)
         return out
 
     def _bind_ops(self) -> None:
         """The operations for the current layout: the plain ones for fp32 / fp64 entries, the
-        rounding ones (appfl_amd.half_ops) when the float entries are bfloat16 / float16."""
+        16-bit ones (appfl_amd.half_ops) when the float entries are bfloat16 / float16."""
         self._ops = half_ops.for_layout(self._layout, self._unrounded_ops())
 
     def _unrounded_ops(self):
-        """`_ops` as it was before a 16-bit layout put the rounding operations in its place."""
+        """`_ops` as it was before a 16-bit layout put the 16-bit operations in its place."""
         if isinstance(self._ops, half_ops.HalfOps):
             return self._plain_ops
         self._plain_ops = self._ops
@@ -159,7 +143,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         if flat is None and flat64 is None:
             return {}
         src = {STEP: flat, STEP_F64: flat64}
-        return {e.name: _narrow(src[e.cls][e.offset:e.offset + e.numel].view(e.shape), e)
+        return {e.name: src[e.cls][e.offset:e.offset + e.numel].view(e.shape)
                 for e in self._layout.entries if src.get(e.cls) is not None}
 
     @property
@@ -190,10 +174,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     sizes = {k: v.numel() * v.element_size() for k, v in source.items()}
                 else:
                     names_layout = self._names_layout()
-                    sizes = {e.name: e.numel * torch.empty((), dtype=e.caller_dtype).element_size()
+                    sizes = {e.name: e.numel * torch.empty((), dtype=e.dtype).element_size()
                              for e in (names_layout.entries if names_layout is not None else [])}
-                    sizes.update({k: v.numel() * torch.empty((), dtype=self._extra_dtype.get(k, v.dtype)).element_size()
-                                  for k, v in self._extra_state.items()})
+                    sizes.update({k: v.numel() * v.element_size() for k, v in self._extra_state.items()})
                 if sum(sizes.values()) > self.model_chunk_size:
                     chunks = split_names_by_size(sizes, self.model_chunk_size)
                     chunk_idx = requested_chunk_id if requested_chunk_id is not None else 0
@@ -246,8 +229,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         """A whole-model round after streamed rounds only: the global state is what the chunks
         built (fedavg_aggregator.py:228 finds `global_state` set), in their order."""
         init, self._extra_state = self._extra_state, {}
-        dtypes, self._extra_dtype = self._extra_dtype, {}
-        self._layout = Layout([(n, tuple(t.shape), dtypes.get(n, t.dtype)) for n, t in init.items()],
+        self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
                               self.named_parameters)
         self._flats = self._layout.alloc_state(self.device)
         for n, t in init.items():
@@ -260,12 +242,11 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         """Fresh CPU copy of the global state: one D2H copy per dtype, entries are views of it."""
         lay = self._layout
         if names is not None:
-            extra = self._extra_exported()
-            return {n: (lay.export(self._flats, n) if lay is not None and n in lay.by_name
-                        else extra[n]).cpu()
-                    for n in names if (lay is not None and n in lay.by_name) or n in extra}
+            return {n: (lay.view(self._flats, n) if lay is not None and n in lay.by_name
+                        else self._extra_state[n]).cpu()
+                    for n in names if (lay is not None and n in lay.by_name) or n in self._extra_state}
         out = _download_flats(lay, self._flats, self._dl) if lay is not None else {}
-        out.update(self._extra_exported(to_cpu=True))
+        out.update({k: v.cpu() for k, v in self._extra_state.items()})
         return out
 
     def _client_weights(self, local_models) -> list:
@@ -457,7 +438,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             n, n64 = lay.count[STEP], lay.count[STEP_F64]
             weights = self._client_weights(local_models)
             if self._step_flat is None:
-                self._step_flat = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+                self._step_flat = torch.empty(max(n, 1), dtype=lay.float_dtype, device=self.device)
             if n:
                 self._ops.reduce_step(self._rows(len(local_models), 0), weights,
                                       self._flats["f32"], self._step_flat, n=n)
@@ -467,7 +448,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 self._ops.reduce_step(self._rows(len(local_models), lay.seg_byte[STEP_F64]), weights,
                                       self._flats["f64"], self._step_flat64, n=n64)
             src = {STEP: self._step_flat, STEP_F64: self._step_flat64}
-            self.step = {e.name: _narrow(src[e.cls][e.offset:e.offset + e.numel].view(e.shape), e)
+            self.step = {e.name: src[e.cls][e.offset:e.offset + e.numel].view(e.shape)
                          for e in lay.entries if e.cls in src}
 
     # whether the plain-mean segments of a round may ride on the fused launch (subclasses whose
@@ -546,7 +527,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 ws = None
                 if K > self._ops.kchunk():
                     if self._step_flat is None:
-                        self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+                        self._step_flat = torch.empty(n_step, dtype=lay.float_dtype, device=self.device)
                     ws = self._step_flat
                 if events:
                     events[0].record()
@@ -568,7 +549,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             for e in lay.entries:
                 if e.name in self.step:
                     st = self.step[e.name]
-                    if st.dtype != e.dtype or st.device != self.device:    # a 16-bit step: into its carrier
+                    if st.dtype != e.dtype or st.device != self.device:    # a user's step in another form
                         st = st.to(device=self.device, dtype=e.dtype)
                     self._ops.apply_step(lay.view(self._flats, e.name).view(-1), st.contiguous().view(-1))
 
@@ -696,7 +677,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         for key, n in (("i64", lay.count[MEAN_I64]), ("i32", lay.count[MEAN_I32])):
             host[key] = self._dl.fetch(self._flats[key], n, wait=False)
         out = lay.views(host)              # while the last transfers are in flight
-        out.update(self._extra_exported(to_cpu=True))
+        out.update({k: v.cpu() for k, v in self._extra_state.items()})
         compute.synchronize()
         down.synchronize()
         return out
@@ -761,13 +742,6 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             return main.view(self._flats, key)
         return self._extra_state.get(key)
 
-    def _state_dtype(self, key) -> torch.dtype:
-        """The dtype the caller sees for entry `key` of the global state."""
-        main = self._names_layout()
-        if main is not None and key in main.by_name:
-            return main.by_name[key].caller_dtype
-        return self._extra_dtype.get(key, self._extra_state[key].dtype)
-
     def _state_written(self, key) -> None:
         """Called after the tensor `_state_value(key)` returned was overwritten (subclasses that
         keep further copies of the state refresh them)."""
@@ -784,19 +758,17 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             first = next(iter(local_models.values()))
             current = self._state_value
 
-            init, dtypes = {}, {}
+            init = {}
             for k in chunk_keys:
                 cur = current(k)
                 if cur is not None:
                     init[k] = cur
-                    dtypes[k] = self._state_dtype(k)
                 elif k in first:
                     init[k] = first[k]
-                    dtypes[k] = first[k].dtype
-            tag = tuple((k, tuple(t.shape), dtypes[k]) for k, t in init.items())
+            tag = tuple((k, tuple(t.shape), t.dtype) for k, t in init.items())
             st = self._chunks.get(tag)
             if st is None:
-                lay = Layout([(n, tuple(t.shape), dtypes[n]) for n, t in init.items()], None)
+                lay = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()], None)
                 st = _ChunkState(lay, lay.alloc_state(self.device), ClientSlab(lay, self.device))
                 self._chunks[tag] = st
             lay, K = st.layout, len(local_models)
@@ -813,7 +785,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             if lay.count[STEP]:
                 ws = None
                 if K > ops_.kchunk():
-                    ws = torch.empty(lay.count[STEP], dtype=torch.float32, device=self.device)
+                    ws = torch.empty(lay.count[STEP], dtype=lay.float_dtype, device=self.device)
                 ops_.reduce_opt(rows(0), self._client_weights(local_models), st.flats["f32"],
                                 step_ws=ws, n=lay.count[STEP])
             if lay.count[STEP_F64]:
@@ -835,8 +807,6 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                         self._state_written(n)
                     else:
                         self._extra_state[n] = lay.view(st.flats, n).clone()
-                        if lay.by_name[n].model_dtype is not None:
-                            self._extra_dtype[n] = lay.by_name[n].model_dtype
             out = _download_flats(lay, st.flats, self._dl)
             self._sync_model(self.model, out)        # partial update (:447-452)
             return {k: out[k] for k in chunk_keys if k in out}
@@ -852,7 +822,7 @@ class FedAvgMAggregator(FedAvgAggregator):
 
     def _ensure_moments(self):
         if self._v is None:   # fedavgm_aggregator.py:37-45
-            self._v = torch.zeros(self._layout.count[STEP], dtype=torch.float32, device=self.device)
+            self._v = torch.zeros(self._layout.count[STEP], dtype=self._layout.float_dtype, device=self.device)
             if self._layout.count[STEP_F64]:
                 self._v64 = torch.zeros(self._layout.count[STEP_F64], dtype=torch.float64, device=self.device)
 
@@ -865,9 +835,6 @@ class FedAvgMAggregator(FedAvgAggregator):
                 self._ensure_moments()
             if n:
                 self._ops.server_opt_step(self._step_flat, self._m, self._v, self._OPT, n=n, **self._hyper())
-                if self._layout.half_dtype is not None:     # `step` holds narrowed copies: take them again
-                    self.step.update({e.name: _narrow(self._step_flat[e.offset:e.offset + e.numel].view(e.shape), e)
-                                      for e in self._layout.entries if e.cls == STEP})
             if n64:
                 self._ops.server_opt_step(self._step_flat64, self._m64, self._v64, self._OPT, n=n64, **self._hyper())
 
@@ -891,8 +858,8 @@ class _AdaptiveAggregator(FedAvgMAggregator):
         if self._m is None:   # fedadam_aggregator.py:41-50: zeros, zeros + tau**2
             n = self._layout.count[STEP]
             tau = cfg_require(self.aggregator_configs, "server_adapt_param")
-            self._m = torch.zeros(n, dtype=torch.float32, device=self.device)
-            self._v = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._m = torch.zeros(n, dtype=self._layout.float_dtype, device=self.device)
+            self._v = torch.empty(n, dtype=self._layout.float_dtype, device=self.device)
             self._ops.fill(self._v, tau ** 2)
             n64 = self._layout.count[STEP_F64]
             if n64:

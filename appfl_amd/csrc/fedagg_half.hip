@@ -6,16 +6,15 @@
 // Python scalar that multiplies or divides such a tensor enters as its fp32 value; one that is
 // added (tau, tau**2) or passed as `alpha=` of add_ / sub_ is first rounded to the tensor's type.
 //
-// Here the values travel in fp32 CARRIERS: device buffers of floats that only ever hold values
-// representable in the 16-bit type (the widening on upload and the narrowing on download are
-// exact).  Every kernel below is the fp32 formula of the entry point of the same name with each
-// operation's result passed through round<HALF>() -- the hardware's round-to-nearest-even
-// conversion to the 16-bit type and back -- so results equal the reference's bit for bit.
-// Carriers cost twice the bytes a 16-bit row format would; these are plain streaming kernels
-// (128-bit loads where the buffers allow it, eight client loads in flight), not the tuned fp32 path.
+// Everything stays 16 bits wide in HBM -- client rows, global state, moments, steps -- so a
+// 16-bit model moves half the bytes of an fp32 one.  A kernel widens what it loads (exact),
+// evaluates the fp32 formula of the entry point of the same name with each operation's result
+// passed through rnd<HALF>() -- the hardware's round-to-nearest-even conversion to the 16-bit
+// type and back -- and narrows what it stores (exact again: every stored value came out of
+// rnd).  Results equal the reference's bit for bit.  Plain streaming kernels: 128-bit loads of
+// eight elements where the buffers allow it, eight client loads in flight.
 
 #include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -23,25 +22,29 @@
 
 namespace {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 1 << 20;
 constexpr int kAhead = 8;   // client loads in flight per element / vector
+constexpr int kWide = 8;    // elements of a 128-bit load
+
+template <int HALF> struct Elem;
+template <> struct Elem<FA_HALF_BF16> { typedef __bf16 T; };
+template <> struct Elem<FA_HALF_F16> { typedef _Float16 T; };
 
 // fp32 -> 16-bit type (round to nearest even) -> fp32.  The empty asm makes the fp32 value
-// opaque to the compiler, so that the conversion stays a conversion of its own: left alone, the
+// opaque to the compiler, so that the conversion stays a conversion of its own.  Left alone, the
 // compiler merges a multiply and the narrowing that follows it into one mixed-precision
-// instruction (v_fma_mixlo_f16), whose results were measured to differ from multiply-then-convert
-// in the last place of about 2 % of the products.
+// instruction (v_fma_mixlo_f16), which rounds the EXACT product once (tools/fma_mix_probe.hip:
+// 4 194 304 of 4 194 304 products), while the reference rounds twice, to fp32 and then to fp16.
+// The two differ whenever the fp32 rounding lands on an fp16 tie, and with a factor like
+// beta1 = 0.9 that is no rarity: 0.9f * m sits just below a tie for every tenth fp16 m, so
+// 4 % of the products m * 0.9f came out one unit in the last place apart.
 template <int HALF>
 __device__ __forceinline__ float rnd(float x) {
     __asm__("" : "+v"(x));
-    if constexpr (HALF == FA_HALF_BF16) {
-        return static_cast<float>(static_cast<__bf16>(x));
-    } else {
-        return static_cast<float>(static_cast<_Float16>(x));
-    }
+    return static_cast<float>(static_cast<typename Elem<HALF>::T>(x));
 }
 
 template <int HALF>
@@ -69,28 +72,73 @@ struct PackH {
     float e[VEC];
 };
 
-template <int VEC, bool NT>
-__device__ __forceinline__ PackH<VEC> load_h(const float* p, size_t i) {
-    PackH<VEC> r;
-    if constexpr (VEC == 4) {
-        const f4* q = reinterpret_cast<const f4*>(p) + i;
-        f4 t = NT ? __builtin_nontemporal_load(q) : *q;
-        r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
+// two 16-bit elements of one dword, widened (exact)
+template <int HALF>
+__device__ __forceinline__ void widen2(unsigned u, float& lo, float& hi) {
+    if constexpr (HALF == FA_HALF_BF16) {
+        lo = __builtin_bit_cast(float, u << 16);
+        hi = __builtin_bit_cast(float, u & 0xFFFF0000u);
     } else {
-        r.e[0] = NT ? __builtin_nontemporal_load(p + i) : p[i];
+        lo = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(u & 0xFFFFu)));
+        hi = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<unsigned short>(u >> 16)));
+    }
+}
+
+// ... and two values that are representable in the 16-bit type, narrowed into one dword (exact)
+template <int HALF>
+__device__ __forceinline__ unsigned narrow2(float lo, float hi) {
+    if constexpr (HALF == FA_HALF_BF16) {
+        return (__builtin_bit_cast(unsigned, lo) >> 16) | (__builtin_bit_cast(unsigned, hi) & 0xFFFF0000u);
+    } else {
+        const unsigned a = __builtin_bit_cast(unsigned short, static_cast<_Float16>(lo));
+        const unsigned b = __builtin_bit_cast(unsigned short, static_cast<_Float16>(hi));
+        return a | (b << 16);
+    }
+}
+
+// element i of width VEC (8: one 128-bit access, 1: one 16-bit access) of a 16-bit buffer
+template <int HALF, int VEC, bool NT>
+__device__ __forceinline__ PackH<VEC> load_h(const void* p, size_t i) {
+    PackH<VEC> r;
+    if constexpr (VEC == kWide) {
+        const u4* q = static_cast<const u4*>(p) + i;
+        const u4 t = NT ? __builtin_nontemporal_load(q) : *q;
+        widen2<HALF>(t.x, r.e[0], r.e[1]);
+        widen2<HALF>(t.y, r.e[2], r.e[3]);
+        widen2<HALF>(t.z, r.e[4], r.e[5]);
+        widen2<HALF>(t.w, r.e[6], r.e[7]);
+    } else {
+        const unsigned short* q = static_cast<const unsigned short*>(p) + i;
+        const unsigned short b = NT ? __builtin_nontemporal_load(q) : *q;
+        float hi;
+        widen2<HALF>(b, r.e[0], hi);
     }
     return r;
 }
 
-template <int VEC>
-__device__ __forceinline__ void store_h(float* p, size_t i, const PackH<VEC>& r) {
-    if constexpr (VEC == 4) {
-        f4 t;
-        t.x = r.e[0]; t.y = r.e[1]; t.z = r.e[2]; t.w = r.e[3];
-        reinterpret_cast<f4*>(p)[i] = t;
+template <int HALF, int VEC>
+__device__ __forceinline__ void store_h(void* p, size_t i, const PackH<VEC>& r) {
+    if constexpr (VEC == kWide) {
+        u4 t;
+        t.x = narrow2<HALF>(r.e[0], r.e[1]);
+        t.y = narrow2<HALF>(r.e[2], r.e[3]);
+        t.z = narrow2<HALF>(r.e[4], r.e[5]);
+        t.w = narrow2<HALF>(r.e[6], r.e[7]);
+        static_cast<u4*>(p)[i] = t;
     } else {
-        p[i] = r.e[0];
+        static_cast<unsigned short*>(p)[i] = static_cast<unsigned short>(narrow2<HALF>(r.e[0], 0.0f) & 0xFFFFu);
     }
+}
+
+template <int HALF>
+__device__ __forceinline__ float ld(const void* p, size_t i) { return load_h<HALF, 1, false>(p, i).e[0]; }
+template <int HALF>
+__device__ __forceinline__ float ld_nt(const void* p, size_t i) { return load_h<HALF, 1, true>(p, i).e[0]; }
+template <int HALF>
+__device__ __forceinline__ void st(void* p, size_t i, float x) {
+    PackH<1> r;
+    r.e[0] = x;
+    store_h<HALF, 1>(p, i, r);
 }
 
 __device__ __forceinline__ float sign_h(float d) {
@@ -130,14 +178,14 @@ __device__ __forceinline__ float optimizer_step_h(float step, float& m, float& v
 }
 
 struct ReduceHArgs {
-    const float* x[FA_KCHUNK];
+    const void* x[FA_KCHUNK];
     float w[FA_KCHUNK];
-    float* g;
-    const float* g_ro;
-    float* m;
-    float* v;
-    const float* step_in;
-    float* step_out;
+    void* g;
+    const void* g_ro;
+    void* m;
+    void* v;
+    const void* step_in;
+    void* step_out;
     size_t n;   // elements of width VEC
     int K, last, apply;
     HyperH h;
@@ -147,10 +195,10 @@ template <int OPT, int HALF, int VEC>
 __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs a) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.n; i += stride) {
-        const PackH<VEC> g = load_h<VEC, false>(a.apply ? a.g : a.g_ro, i);
+        const PackH<VEC> g = load_h<HALF, VEC, false>(a.apply ? a.g : a.g_ro, i);
         PackH<VEC> s;
         if (a.step_in) {
-            s = load_h<VEC, false>(a.step_in, i);
+            s = load_h<HALF, VEC, false>(a.step_in, i);
         } else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) s.e[e] = 0.0f;
@@ -159,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs
         for (; k + kAhead <= a.K; k += kAhead) {
             PackH<VEC> x[kAhead];
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) x[u] = load_h<VEC, true>(a.x[k + u], i);
+            for (int u = 0; u < kAhead; ++u) x[u] = load_h<HALF, VEC, true>(a.x[k + u], i);
 #pragma unroll
             for (int u = 0; u < kAhead; ++u) {
                 const float w = a.w[k + u];
@@ -172,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs
             }
         }
         for (; k < a.K; ++k) {
-            const PackH<VEC> x = load_h<VEC, true>(a.x[k], i);
+            const PackH<VEC> x = load_h<HALF, VEC, true>(a.x[k], i);
             const float w = a.w[k];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -182,56 +230,56 @@ __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs
             }
         }
         if (!a.last) {
-            store_h<VEC>(a.step_out, i, s);
+            store_h<HALF, VEC>(a.step_out, i, s);
             continue;
         }
         if (OPT != FA_OPT_NONE) {
-            PackH<VEC> v = load_h<VEC, false>(a.v, i);
+            PackH<VEC> v = load_h<HALF, VEC, false>(a.v, i);
             PackH<VEC> m;
             if (OPT != FA_OPT_AVGM) {
-                m = load_h<VEC, false>(a.m, i);
+                m = load_h<HALF, VEC, false>(a.m, i);
             } else {
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) m.e[e] = 0.0f;
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) s.e[e] = optimizer_step_h<OPT, HALF>(s.e[e], m.e[e], v.e[e], a.h);
-            store_h<VEC>(a.v, i, v);
-            if (OPT != FA_OPT_AVGM) store_h<VEC>(a.m, i, m);
+            store_h<HALF, VEC>(a.v, i, v);
+            if (OPT != FA_OPT_AVGM) store_h<HALF, VEC>(a.m, i, m);
         }
-        if (a.step_out) store_h<VEC>(a.step_out, i, s);
+        if (a.step_out) store_h<HALF, VEC>(a.step_out, i, s);
         if (a.apply) {
             PackH<VEC> r;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) r.e[e] = rnd<HALF>(g.e[e] + s.e[e]);
-            store_h<VEC>(a.g, i, r);
+            store_h<HALF, VEC>(a.g, i, r);
         }
     }
 }
 
 template <int OPT, int HALF>
-__global__ __launch_bounds__(kThreads) void opt_step_half_kernel(float* step, float* m, float* v, HyperH h, size_t n) {
+__global__ __launch_bounds__(kThreads) void opt_step_half_kernel(void* step, void* m, void* v, HyperH h, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
-        float vv = v[i];
-        float mm = (OPT != FA_OPT_AVGM) ? m[i] : 0.0f;
-        step[i] = optimizer_step_h<OPT, HALF>(step[i], mm, vv, h);
-        v[i] = vv;
-        if (OPT != FA_OPT_AVGM) m[i] = mm;
+        float vv = ld<HALF>(v, i);
+        float mm = (OPT != FA_OPT_AVGM) ? ld<HALF>(m, i) : 0.0f;
+        st<HALF>(step, i, optimizer_step_h<OPT, HALF>(ld<HALF>(step, i), mm, vv, h));
+        st<HALF>(v, i, vv);
+        if (OPT != FA_OPT_AVGM) st<HALF>(m, i, mm);
     }
 }
 
 template <int HALF>
-__global__ __launch_bounds__(kThreads) void apply_half_kernel(float* g, const float* step, size_t n) {
+__global__ __launch_bounds__(kThreads) void apply_half_kernel(void* g, const void* step, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride)
-        g[i] = rnd<HALF>(g[i] + step[i]);
+        st<HALF>(g, i, rnd<HALF>(ld<HALF>(g, i) + ld<HALF>(step, i)));
 }
 
 struct MeanHArgs {
-    const float* x[FA_KCHUNK];
-    float* g;
-    const float* sum_in;
+    const void* x[FA_KCHUNK];
+    void* g;
+    const void* sum_in;
     size_t n;
     int K, last;
     float Kall;
@@ -242,9 +290,9 @@ template <int HALF>
 __global__ __launch_bounds__(kThreads) void mean_half_kernel(const MeanHArgs a) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.n; i += stride) {
-        float s = a.sum_in ? a.sum_in[i] : 0.0f;
-        for (int k = 0; k < a.K; ++k) s = rnd<HALF>(s + __builtin_nontemporal_load(a.x[k] + i));
-        a.g[i] = a.last ? rnd<HALF>(s / a.Kall) : s;
+        float s = a.sum_in ? ld<HALF>(a.sum_in, i) : 0.0f;
+        for (int k = 0; k < a.K; ++k) s = rnd<HALF>(s + ld_nt<HALF>(a.x[k], i));
+        st<HALF>(a.g, i, a.last ? rnd<HALF>(s / a.Kall) : s);
     }
 }
 
@@ -264,44 +312,53 @@ __device__ __forceinline__ float async_step_h(float x, float g, float alpha) {
     return rnd<HALF>(alpha * nx);
 }
 
-template <int MODE, int HALF>
-__global__ __launch_bounds__(kThreads) void async_mix_half_kernel(const float* x, float alpha, float* g, float* step_out, size_t n) {
+// One arrival over 16-bit buffers, VEC elements per thread.  BUFF = false is the FedAsync mix
+// (g = g + step, `step` optional output); BUFF = true the FedBuff accumulate (the buffer `step`
+// grows by the arrival's step; with flush != 0 also g = g + buffer).
+template <int MODE, int HALF, int VEC, bool BUFF>
+__global__ __launch_bounds__(kThreads) void arrival_half_kernel(const void* x, float alpha, void* g, void* step, int first, int flush, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
-        const float gv = g[i];
-        const float s = async_step_h<MODE, HALF>(__builtin_nontemporal_load(x + i), gv, alpha);
-        if (step_out) step_out[i] = s;
-        g[i] = rnd<HALF>(gv + s);
-    }
-}
-
-template <int MODE, int HALF>
-__global__ __launch_bounds__(kThreads) void buff_accum_half_kernel(const float* x, float alpha, float* g, float* step, int first, int flush, size_t n) {
-    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
-        const float gv = g[i];
-        float s = first ? 0.0f : step[i];
-        const float d = async_step_h<MODE, HALF>(__builtin_nontemporal_load(x + i), gv, alpha);
-        s = rnd<HALF>(s + d);
-        step[i] = s;
-        if (flush) g[i] = rnd<HALF>(gv + s);
-    }
-}
-
-template <int HALF>
-__global__ __launch_bounds__(kThreads) void accum_raw_half_kernel(const float* x, float* step, int first, size_t n) {
-    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
-        const float s = first ? 0.0f : step[i];
-        step[i] = rnd<HALF>(s + x[i]);
+        const PackH<VEC> gv = load_h<HALF, VEC, false>(g, i);
+        const PackH<VEC> xv = load_h<HALF, VEC, true>(x, i);
+        PackH<VEC> s, r;
+        if (BUFF && !first) {
+            s = load_h<HALF, VEC, false>(step, i);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s.e[e] = 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float d = async_step_h<MODE, HALF>(xv.e[e], gv.e[e], alpha);
+            s.e[e] = BUFF ? rnd<HALF>(s.e[e] + d) : d;
+            r.e[e] = rnd<HALF>(gv.e[e] + s.e[e]);
+        }
+        if (BUFF || step) store_h<HALF, VEC>(step, i, s);
+        if (!BUFF || flush) store_h<HALF, VEC>(g, i, r);
     }
 }
 
 template <int HALF>
-__global__ __launch_bounds__(kThreads) void flush_mean_half_kernel(float* g, const float* step, float kf, size_t n) {
+__global__ __launch_bounds__(kThreads) void accum_raw_half_kernel(const void* x, void* step, int first, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        const float s = first ? 0.0f : ld<HALF>(step, i);
+        st<HALF>(step, i, rnd<HALF>(s + ld<HALF>(x, i)));
+    }
+}
+
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void flush_mean_half_kernel(void* g, const void* step, float kf, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
     for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride)
-        g[i] = rnd<HALF>(step[i] / kf);
+        st<HALF>(g, i, rnd<HALF>(ld<HALF>(step, i) / kf));
+}
+
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void fill_half_kernel(void* p, float value, size_t n) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) st<HALF>(p, i, value);
 }
 
 inline hipStream_t as_stream(fa_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -309,13 +366,15 @@ inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FA_OK : FA_ERR_HIP - static_cast<int>(e);
 }
-inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+inline bool aligned2(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 1u) == 0; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool known(int half) { return half == FA_HALF_BF16 || half == FA_HALF_F16; }
 inline unsigned grid_for(size_t n) {
     size_t b = (n + kThreads - 1) / kThreads;
     return static_cast<unsigned>(b < 1 ? 1 : (b > static_cast<size_t>(kMaxBlocks) ? kMaxBlocks : b));
 }
+inline const void* at(const void* p, size_t elements) { return p ? static_cast<const char*>(p) + 2 * elements : nullptr; }
+inline void* at(void* p, size_t elements) { return p ? static_cast<char*>(p) + 2 * elements : nullptr; }
 
 HyperH make_hyper_h(double lr, double beta1, double beta2, double tau, int half) {
     return HyperH{static_cast<float>(lr), static_cast<float>(beta1), static_cast<float>(1.0 - beta1),
@@ -335,8 +394,8 @@ void launch_reduce_half(int opt, const ReduceHArgs& a, hipStream_t st) {
     }
 }
 
-int reduce_half(const float* const* x, const double* w, int K, float* g, const float* g_ro, float* m, float* v,
-                size_t n, int opt, const HyperH& h, float* step_out, float* step_ws, int apply, int half,
+int reduce_half(const void* const* x, const double* w, int K, void* g, const void* g_ro, void* m, void* v,
+                size_t n, int opt, const HyperH& h, void* step_out, void* step_ws, int apply, int half,
                 hipStream_t st) {
     if (!x || !w || K <= 0 || !known(half)) return FA_ERR_INVALID;
     if (apply ? !g : (!g_ro || !step_out)) return FA_ERR_INVALID;
@@ -347,19 +406,20 @@ int reduce_half(const float* const* x, const double* w, int K, float* g, const f
     const void* ptrs[] = {g, g_ro, m, v, step_out, step_ws};
     bool wide = true;
     for (const void* p : ptrs) {
-        if (p && !aligned4(p)) return FA_ERR_ALIGN;
+        if (p && !aligned2(p)) return FA_ERR_ALIGN;
         wide = wide && (!p || aligned16(p));
     }
     for (int k = 0; k < K; ++k) {
         if (!x[k]) return FA_ERR_INVALID;
-        if (!aligned4(x[k])) return FA_ERR_ALIGN;
+        if (!aligned2(x[k])) return FA_ERR_ALIGN;
         wide = wide && aligned16(x[k]);
     }
     if (n == 0) return FA_OK;
     const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
-    float* carry = step_out ? step_out : step_ws;
-    // 128-bit body over the leading whole vectors when every buffer allows it, scalar kernel over the rest
-    const size_t body = wide ? n / 4 * 4 : 0;
+    void* carry = step_out ? step_out : step_ws;
+    // 128-bit body over the leading whole vectors when every buffer allows it, the 16-bit-access
+    // kernel over the rest
+    const size_t body = wide ? n / kWide * kWide : 0;
     for (int ch = 0; ch < chunks; ++ch) {
         ReduceHArgs a;
         memset(&a, 0, sizeof(a));
@@ -373,19 +433,18 @@ int reduce_half(const float* const* x, const double* w, int K, float* g, const f
             const size_t lo = part ? body : 0, cnt = part ? n - body : body;
             if (cnt == 0) continue;
             for (int k = 0; k < a.K; ++k) {
-                a.x[k] = x[k0 + k] + lo;
+                a.x[k] = at(x[k0 + k], lo);
                 a.w[k] = static_cast<float>(w[k0 + k]);
             }
-            a.g = g ? g + lo : nullptr;
-            a.g_ro = g_ro ? g_ro + lo : nullptr;
-            a.m = m ? m + lo : nullptr;
-            a.v = v ? v + lo : nullptr;
-            a.step_in = (ch == 0) ? nullptr : carry + lo;
-            float* so = a.last ? step_out : carry;
-            a.step_out = so ? so + lo : nullptr;
+            a.g = at(g, lo);
+            a.g_ro = at(g_ro, lo);
+            a.m = at(m, lo);
+            a.v = at(v, lo);
+            a.step_in = (ch == 0) ? nullptr : at(static_cast<const void*>(carry), lo);
+            a.step_out = at(a.last ? step_out : carry, lo);
             if (part == 0) {
-                a.n = cnt / 4;
-                if (half == FA_HALF_BF16) launch_reduce_half<FA_HALF_BF16, 4>(o, a, st); else launch_reduce_half<FA_HALF_F16, 4>(o, a, st);
+                a.n = cnt / kWide;
+                if (half == FA_HALF_BF16) launch_reduce_half<FA_HALF_BF16, kWide>(o, a, st); else launch_reduce_half<FA_HALF_F16, kWide>(o, a, st);
             } else {
                 a.n = cnt;
                 if (half == FA_HALF_BF16) launch_reduce_half<FA_HALF_BF16, 1>(o, a, st); else launch_reduce_half<FA_HALF_F16, 1>(o, a, st);
@@ -397,32 +456,32 @@ int reduce_half(const float* const* x, const double* w, int K, float* g, const f
     return FA_OK;
 }
 
-template <int HALF>
-int async_half(const float* x, float alpha, int gradient_based, int sub_form, float* g, float* step_out,
-               size_t n, hipStream_t st) {
-    const dim3 grid(grid_for(n)), block(kThreads);
+template <int MODE, int HALF, bool BUFF>
+void launch_arrival(const void* x, float alpha, void* g, void* step, int first, int flush, size_t n, hipStream_t st) {
+    const bool wide = aligned16(x) && aligned16(g) && (!step || aligned16(step));
+    const size_t body = wide ? n / kWide * kWide : 0;
+    if (body)
+        hipLaunchKernelGGL((arrival_half_kernel<MODE, HALF, kWide, BUFF>), dim3(grid_for(body / kWide)), dim3(kThreads), 0,
+                           st, x, alpha, g, step, first, flush, body / kWide);
+    if (n > body)
+        hipLaunchKernelGGL((arrival_half_kernel<MODE, HALF, 1, BUFF>), dim3(grid_for(n - body)), dim3(kThreads), 0, st,
+                           at(x, body), alpha, at(g, body), at(step, body), first, flush, n - body);
+}
+
+template <int HALF, bool BUFF>
+int arrival_half(const void* x, float alpha, int gradient_based, int sub_form, void* g, void* step, int first,
+                 int flush, size_t n, hipStream_t st) {
     if (!gradient_based)
-        hipLaunchKernelGGL((async_mix_half_kernel<0, HALF>), grid, block, 0, st, x, alpha, g, step_out, n);
+        launch_arrival<0, HALF, BUFF>(x, alpha, g, step, first, flush, n, st);
     else if (sub_form)
-        hipLaunchKernelGGL((async_mix_half_kernel<1, HALF>), grid, block, 0, st, x, alpha, g, step_out, n);
+        launch_arrival<1, HALF, BUFF>(x, alpha, g, step, first, flush, n, st);
     else
-        hipLaunchKernelGGL((async_mix_half_kernel<2, HALF>), grid, block, 0, st, x, alpha, g, step_out, n);
+        launch_arrival<2, HALF, BUFF>(x, alpha, g, step, first, flush, n, st);
     return launch_status();
 }
 
 template <int HALF>
-int buff_half(const float* x, float alpha, int gradient_based, float* g, float* step, int first, int flush,
-              size_t n, hipStream_t st) {
-    const dim3 grid(grid_for(n)), block(kThreads);
-    if (gradient_based)
-        hipLaunchKernelGGL((buff_accum_half_kernel<2, HALF>), grid, block, 0, st, x, alpha, g, step, first, flush, n);
-    else
-        hipLaunchKernelGGL((buff_accum_half_kernel<0, HALF>), grid, block, 0, st, x, alpha, g, step, first, flush, n);
-    return launch_status();
-}
-
-template <int HALF>
-int opt_step_half(float* step, float* m, float* v, size_t n, int opt, const HyperH& h, hipStream_t st) {
+int opt_step_half(void* step, void* m, void* v, size_t n, int opt, const HyperH& h, hipStream_t st) {
     const dim3 grid(grid_for(n)), block(kThreads);
     switch (opt) {
         case FA_OPT_AVGM: hipLaunchKernelGGL((opt_step_half_kernel<FA_OPT_AVGM, HALF>), grid, block, 0, st, step, m, v, h, n); break;
@@ -441,35 +500,35 @@ float fa_half_round_scalar(double x, int half) {
     return known(half) ? rnd_host(static_cast<float>(x), half) : static_cast<float>(x);
 }
 
-int fa_half_reduce_opt(const float* const* x, const double* w, int K, float* g, float* m, float* v, size_t n,
-                       int opt, double lr, double beta1, double beta2, double tau, float* step_out,
-                       float* step_ws, int half, fa_stream_t stream) {
+int fa_half_reduce_opt(const void* const* x, const double* w, int K, void* g, void* m, void* v, size_t n,
+                       int opt, double lr, double beta1, double beta2, double tau, void* step_out,
+                       void* step_ws, int half, fa_stream_t stream) {
     return reduce_half(x, w, K, g, nullptr, m, v, n, opt, make_hyper_h(lr, beta1, beta2, tau, half), step_out,
                        step_ws, 1, half, as_stream(stream));
 }
 
-int fa_half_reduce_step(const float* const* x, const double* w, int K, const float* g, float* step_out,
-                        size_t n, int half, fa_stream_t stream) {
+int fa_half_reduce_step(const void* const* x, const double* w, int K, const void* g, void* step_out, size_t n,
+                        int half, fa_stream_t stream) {
     return reduce_half(x, w, K, nullptr, g, nullptr, nullptr, n, FA_OPT_NONE, make_hyper_h(0, 0, 0, 0, half),
                        step_out, nullptr, 0, half, as_stream(stream));
 }
 
-int fa_half_server_opt_step(float* step, float* m, float* v, size_t n, int opt, double lr, double beta1,
+int fa_half_server_opt_step(void* step, void* m, void* v, size_t n, int opt, double lr, double beta1,
                             double beta2, double tau, int half, fa_stream_t stream) {
     if (!known(half)) return FA_ERR_INVALID;
     if (opt == FA_OPT_NONE) return FA_OK;
     if (opt < FA_OPT_NONE || opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
     if (!step || !v || (opt >= FA_OPT_ADAM && !m)) return FA_ERR_INVALID;
-    if (!aligned4(step) || !aligned4(v) || (m && !aligned4(m))) return FA_ERR_ALIGN;
+    if (!aligned2(step) || !aligned2(v) || (m && !aligned2(m))) return FA_ERR_ALIGN;
     if (n == 0) return FA_OK;
     const HyperH h = make_hyper_h(lr, beta1, beta2, tau, half);
     return half == FA_HALF_BF16 ? opt_step_half<FA_HALF_BF16>(step, m, v, n, opt, h, as_stream(stream))
                                 : opt_step_half<FA_HALF_F16>(step, m, v, n, opt, h, as_stream(stream));
 }
 
-int fa_half_apply_step(float* g, const float* step, size_t n, int half, fa_stream_t stream) {
+int fa_half_apply_step(void* g, const void* step, size_t n, int half, fa_stream_t stream) {
     if (!g || !step || !known(half)) return FA_ERR_INVALID;
-    if (!aligned4(g) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (!aligned2(g) || !aligned2(step)) return FA_ERR_ALIGN;
     if (n == 0) return FA_OK;
     const dim3 grid(grid_for(n)), block(kThreads);
     if (half == FA_HALF_BF16)
@@ -479,12 +538,12 @@ int fa_half_apply_step(float* g, const float* step, size_t n, int half, fa_strea
     return launch_status();
 }
 
-int fa_half_mean(const float* const* x, int K, float* g, size_t n, int half, fa_stream_t stream) {
+int fa_half_mean(const void* const* x, int K, void* g, size_t n, int half, fa_stream_t stream) {
     if (!x || !g || K <= 0 || !known(half)) return FA_ERR_INVALID;
-    if (!aligned4(g)) return FA_ERR_ALIGN;
+    if (!aligned2(g)) return FA_ERR_ALIGN;
     for (int k = 0; k < K; ++k) {
         if (!x[k]) return FA_ERR_INVALID;
-        if (!aligned4(x[k])) return FA_ERR_ALIGN;
+        if (!aligned2(x[k])) return FA_ERR_ALIGN;
     }
     if (n == 0) return FA_OK;
     const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
@@ -510,34 +569,34 @@ int fa_half_mean(const float* const* x, int K, float* g, size_t n, int half, fa_
     return FA_OK;
 }
 
-int fa_half_async_mix(const float* x, double alpha_t, int gradient_based, int sub_form, float* g,
-                      float* step_out, size_t n, int half, fa_stream_t stream) {
+int fa_half_async_mix(const void* x, double alpha_t, int gradient_based, int sub_form, void* g, void* step_out,
+                      size_t n, int half, fa_stream_t stream) {
     if (!x || !g || !known(half)) return FA_ERR_INVALID;
-    if (!aligned4(x) || !aligned4(g) || (step_out && !aligned4(step_out))) return FA_ERR_ALIGN;
+    if (!aligned2(x) || !aligned2(g) || (step_out && !aligned2(step_out))) return FA_ERR_ALIGN;
     if (n == 0) return FA_OK;
     // sub_form = the reference's optimize_memory branch, which passes alpha_t as `alpha=` of
     // add_ / sub_ (fedasync_aggregator.py:246-258): PyTorch casts that scalar to the tensor's type
     float alpha = static_cast<float>(alpha_t);
     if (sub_form) alpha = rnd_host(alpha, half);
     return half == FA_HALF_BF16
-               ? async_half<FA_HALF_BF16>(x, alpha, gradient_based, sub_form, g, step_out, n, as_stream(stream))
-               : async_half<FA_HALF_F16>(x, alpha, gradient_based, sub_form, g, step_out, n, as_stream(stream));
+               ? arrival_half<FA_HALF_BF16, false>(x, alpha, gradient_based, sub_form, g, step_out, 0, 0, n, as_stream(stream))
+               : arrival_half<FA_HALF_F16, false>(x, alpha, gradient_based, sub_form, g, step_out, 0, 0, n, as_stream(stream));
 }
 
-int fa_half_buff_accum(const float* x, double alpha_t, int gradient_based, float* g, float* step, int first,
+int fa_half_buff_accum(const void* x, double alpha_t, int gradient_based, void* g, void* step, int first,
                        int flush, size_t n, int half, fa_stream_t stream) {
     if (!x || !g || !step || !known(half)) return FA_ERR_INVALID;
-    if (!aligned4(x) || !aligned4(g) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (!aligned2(x) || !aligned2(g) || !aligned2(step)) return FA_ERR_ALIGN;
     if (n == 0) return FA_OK;
     const float alpha = static_cast<float>(alpha_t);
     return half == FA_HALF_BF16
-               ? buff_half<FA_HALF_BF16>(x, alpha, gradient_based, g, step, first, flush, n, as_stream(stream))
-               : buff_half<FA_HALF_F16>(x, alpha, gradient_based, g, step, first, flush, n, as_stream(stream));
+               ? arrival_half<FA_HALF_BF16, true>(x, alpha, gradient_based, 0, g, step, first, flush, n, as_stream(stream))
+               : arrival_half<FA_HALF_F16, true>(x, alpha, gradient_based, 0, g, step, first, flush, n, as_stream(stream));
 }
 
-int fa_half_buff_accum_raw(const float* x, float* step, int first, size_t n, int half, fa_stream_t stream) {
+int fa_half_buff_accum_raw(const void* x, void* step, int first, size_t n, int half, fa_stream_t stream) {
     if (!x || !step || !known(half)) return FA_ERR_INVALID;
-    if (!aligned4(x) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (!aligned2(x) || !aligned2(step)) return FA_ERR_ALIGN;
     if (n == 0) return FA_OK;
     const dim3 grid(grid_for(n)), block(kThreads);
     if (half == FA_HALF_BF16)
@@ -547,9 +606,9 @@ int fa_half_buff_accum_raw(const float* x, float* step, int first, size_t n, int
     return launch_status();
 }
 
-int fa_half_buff_flush_mean(float* g, const float* step, int K, size_t n, int half, fa_stream_t stream) {
+int fa_half_buff_flush_mean(void* g, const void* step, int K, size_t n, int half, fa_stream_t stream) {
     if (!g || !step || K <= 0 || !known(half)) return FA_ERR_INVALID;
-    if (!aligned4(g) || !aligned4(step)) return FA_ERR_ALIGN;
+    if (!aligned2(g) || !aligned2(step)) return FA_ERR_ALIGN;
     if (n == 0) return FA_OK;
     const dim3 grid(grid_for(n)), block(kThreads);
     if (half == FA_HALF_BF16)
@@ -558,6 +617,19 @@ int fa_half_buff_flush_mean(float* g, const float* step, int K, size_t n, int ha
     else
         hipLaunchKernelGGL((flush_mean_half_kernel<FA_HALF_F16>), grid, block, 0, as_stream(stream), g, step,
                            static_cast<float>(K), n);
+    return launch_status();
+}
+
+int fa_half_fill(void* p, double value, size_t n, int half, fa_stream_t stream) {
+    if (!p || !known(half)) return FA_ERR_INVALID;
+    if (!aligned2(p)) return FA_ERR_ALIGN;
+    if (n == 0) return FA_OK;
+    const float v = rnd_host(static_cast<float>(value), half);
+    const dim3 grid(grid_for(n)), block(kThreads);
+    if (half == FA_HALF_BF16)
+        hipLaunchKernelGGL((fill_half_kernel<FA_HALF_BF16>), grid, block, 0, as_stream(stream), p, v, n);
+    else
+        hipLaunchKernelGGL((fill_half_kernel<FA_HALF_F16>), grid, block, 0, as_stream(stream), p, v, n);
     return launch_status();
 }
 

@@ -1,13 +1,13 @@
 """The flat-vector operations for bfloat16 / float16 state dicts.
 
-A 16-bit float entry rides in an fp32 CARRIER on the device (see :mod:`appfl_amd.layout`): the
-flat vectors, the client rows and the moments stay fp32 tensors that only hold values
-representable in the 16-bit type.  :class:`HalfOps` has the function names and arguments of
-:mod:`appfl_amd.ops` and sends every call on fp32 tensors to the ``fa_half_*`` entry points, which
-round each operation's result to the 16-bit type exactly where PyTorch's CPU kernels round it in
-the reference (the float path of misc/memory_utils.py:112-131 on a 16-bit tensor); calls on
-integer or float64 tensors pass through to :mod:`appfl_amd.ops`.  It deliberately lacks
-`round_sync` and `RoundPlan`: the aggregators test for those before taking their fused and
+A 16-bit model stays 16 bits wide on the device: client rows, the global state, the moments and
+the steps are bfloat16 / float16 tensors, half the bytes of an fp32 model everywhere.
+:class:`HalfOps` has the function names and arguments of :mod:`appfl_amd.ops` and sends every
+call on tensors of its 16-bit type to the ``fa_half_*`` entry points, which widen on load, round
+each operation's result to the 16-bit type exactly where PyTorch's CPU kernels round it in the
+reference (the float path of misc/memory_utils.py:112-131 on a 16-bit tensor) and narrow on
+store; calls on integer or float64 tensors pass through to :mod:`appfl_amd.ops`.  It deliberately
+lacks `round_sync` and `RoundPlan`: the aggregators test for those before taking their fused and
 pipelined fp32 paths, so a 16-bit layout runs the plain sequence of launches.
 """
 
@@ -22,7 +22,6 @@ from . import ops
 from .ops import OPT_CODES, _check_rows, _dev, _stream
 
 HALF_CODES = {torch.bfloat16: N.FA_HALF_BF16, torch.float16: N.FA_HALF_F16}
-_F32 = torch.float32
 
 
 class HalfOps:
@@ -30,9 +29,7 @@ class HalfOps:
         self.dtype = dtype
         self.half = HALF_CODES[dtype]
 
-    # pass-throughs that do no arithmetic on carriers
     kchunk = staticmethod(ops.kchunk)
-    synth_fill = staticmethod(ops.synth_fill)
 
     def round_scalar(self, x: float) -> float:
         """`x` as the 16-bit type holds it (fa_half_round_scalar)."""
@@ -42,8 +39,9 @@ class HalfOps:
                    opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
                    tau: float = 0.0, step_out=None, step_ws=None, n: Optional[int] = None,
                    persistent: bool = True) -> None:
-        if g.dtype != _F32:
+        if g.dtype != self.dtype:
             return ops.reduce_opt(x, w, g, m, v, opt, lr, beta1, beta2, tau, step_out, step_ws, n)
+        dt = self.dtype
         n = g.numel() if n is None else n
         if len(x) != len(w):
             raise ValueError("one weight per client buffer")
@@ -51,52 +49,54 @@ class HalfOps:
             if t is not None and t.numel() < n:
                 raise ValueError("state / workspace tensor shorter than n")
         rc = N.load().fa_half_reduce_opt(
-            _check_rows(x, n, _F32), N.double_array([float(t) for t in w]), len(x), _dev(g, _F32),
-            _dev(m, _F32), _dev(v, _F32), n, OPT_CODES[opt], float(lr), float(beta1), float(beta2),
-            float(tau), _dev(step_out, _F32), _dev(step_ws, _F32), self.half, _stream(g))
+            _check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x), _dev(g, dt),
+            _dev(m, dt), _dev(v, dt), n, OPT_CODES[opt], float(lr), float(beta1), float(beta2),
+            float(tau), _dev(step_out, dt), _dev(step_ws, dt), self.half, _stream(g))
         N.check(rc, "fa_half_reduce_opt")
 
     def reduce_step(self, x, w, g, step_out, n: Optional[int] = None, k_done: int = 0) -> None:
-        if g.dtype != _F32:
+        if g.dtype != self.dtype:
             return ops.reduce_step(x, w, g, step_out, n, k_done)
         if k_done:
             raise NotImplementedError("resumed steps are fp32 only")
+        dt = self.dtype
         n = g.numel() if n is None else n
         if step_out.numel() < n:
             raise ValueError("step_out shorter than n")
         rc = N.load().fa_half_reduce_step(
-            _check_rows(x, n, _F32), N.double_array([float(t) for t in w]), len(x), _dev(g, _F32),
-            _dev(step_out, _F32), n, self.half, _stream(g))
+            _check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x), _dev(g, dt),
+            _dev(step_out, dt), n, self.half, _stream(g))
         N.check(rc, "fa_half_reduce_step")
 
     def server_opt_step(self, step, m, v, opt: str, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
                         n: Optional[int] = None) -> None:
-        if step.dtype != _F32:
+        if step.dtype != self.dtype:
             return ops.server_opt_step(step, m, v, opt, lr, beta1, beta2, tau, n)
+        dt = self.dtype
         n = step.numel() if n is None else n
         for t in (m, v):
             if t is not None and t.numel() < n:
                 raise ValueError("moment tensor shorter than n")
         rc = N.load().fa_half_server_opt_step(
-            _dev(step, _F32), _dev(m, _F32), _dev(v, _F32), n, OPT_CODES[opt], float(lr), float(beta1),
+            _dev(step, dt), _dev(m, dt), _dev(v, dt), n, OPT_CODES[opt], float(lr), float(beta1),
             float(beta2), float(tau), self.half, _stream(step))
         N.check(rc, "fa_half_server_opt_step")
 
     def apply_step(self, g, step, n: Optional[int] = None) -> None:
-        if g.dtype != _F32:
+        if g.dtype != self.dtype:
             return ops.apply_step(g, step, n)
         n = g.numel() if n is None else n
         if step.numel() < n:
             raise ValueError("step shorter than n")
-        N.check(N.load().fa_half_apply_step(_dev(g, _F32), _dev(step, _F32), n, self.half, _stream(g)),
-                "fa_half_apply_step")
+        N.check(N.load().fa_half_apply_step(_dev(g, self.dtype), _dev(step, self.dtype), n, self.half,
+                                            _stream(g)), "fa_half_apply_step")
 
     def mean(self, x: Sequence, g: torch.Tensor, n: Optional[int] = None) -> None:
-        if g.dtype != _F32:
+        if g.dtype != self.dtype:
             return ops.mean(x, g, n)
         n = g.numel() if n is None else n
-        N.check(N.load().fa_half_mean(_check_rows(x, n, _F32), len(x), _dev(g, _F32), n, self.half,
-                                      _stream(g)), "fa_half_mean")
+        N.check(N.load().fa_half_mean(_check_rows(x, n, self.dtype), len(x), _dev(g, self.dtype), n,
+                                      self.half, _stream(g)), "fa_half_mean")
 
     def weighted_mix(self, *args, **kwargs):
         raise NotImplementedError(
@@ -105,50 +105,58 @@ class HalfOps:
 
     def async_mix(self, x, alpha_t: float, g, gradient_based: bool = False, sub_form: bool = True,
                   step_out=None, n: Optional[int] = None) -> None:
-        if g.dtype != _F32:
+        if g.dtype != self.dtype:
             return ops.async_mix(x, alpha_t, g, gradient_based, sub_form, step_out, n)
+        dt = self.dtype
         n = g.numel() if n is None else n
         if x.numel() < n:
             raise ValueError("x shorter than n")
-        rc = N.load().fa_half_async_mix(_dev(x, _F32), float(alpha_t), int(bool(gradient_based)),
-                                        int(bool(sub_form)), _dev(g, _F32), _dev(step_out, _F32), n,
+        rc = N.load().fa_half_async_mix(_dev(x, dt), float(alpha_t), int(bool(gradient_based)),
+                                        int(bool(sub_form)), _dev(g, dt), _dev(step_out, dt), n,
                                         self.half, _stream(g))
         N.check(rc, "fa_half_async_mix")
 
     def buff_accum(self, x, alpha_t: float, g, step, first: bool, gradient_based: bool = False,
                    flush: bool = False, n: Optional[int] = None) -> None:
-        if g.dtype != _F32:
+        if g.dtype != self.dtype:
             return ops.buff_accum(x, alpha_t, g, step, first, gradient_based, flush, n)
+        dt = self.dtype
         n = g.numel() if n is None else n
         if x.numel() < n or step.numel() < n:
             raise ValueError("x / step shorter than n")
-        rc = N.load().fa_half_buff_accum(_dev(x, _F32), float(alpha_t), int(bool(gradient_based)),
-                                         _dev(g, _F32), _dev(step, _F32), int(bool(first)),
+        rc = N.load().fa_half_buff_accum(_dev(x, dt), float(alpha_t), int(bool(gradient_based)),
+                                         _dev(g, dt), _dev(step, dt), int(bool(first)),
                                          int(bool(flush)), n, self.half, _stream(g))
         N.check(rc, "fa_half_buff_accum")
 
     def buff_accum_raw(self, x, step, first: bool, n: Optional[int] = None) -> None:
-        if step.dtype != _F32:
+        if step.dtype != self.dtype:
             return ops.buff_accum_raw(x, step, first, n)
         n = step.numel() if n is None else n
         if x.numel() < n:
             raise ValueError("x shorter than n")
-        N.check(N.load().fa_half_buff_accum_raw(_dev(x, _F32), _dev(step, _F32), int(bool(first)), n,
-                                                self.half, _stream(step)), "fa_half_buff_accum_raw")
+        N.check(N.load().fa_half_buff_accum_raw(_dev(x, self.dtype), _dev(step, self.dtype),
+                                                int(bool(first)), n, self.half, _stream(step)),
+                "fa_half_buff_accum_raw")
 
     def buff_flush_mean(self, g, step, K: int, n: Optional[int] = None) -> None:
-        if g.dtype != _F32:
+        if g.dtype != self.dtype:
             return ops.buff_flush_mean(g, step, K, n)
         n = g.numel() if n is None else n
         if step.numel() < n:
             raise ValueError("step shorter than n")
-        N.check(N.load().fa_half_buff_flush_mean(_dev(g, _F32), _dev(step, _F32), int(K), n, self.half,
-                                                 _stream(g)), "fa_half_buff_flush_mean")
+        N.check(N.load().fa_half_buff_flush_mean(_dev(g, self.dtype), _dev(step, self.dtype), int(K), n,
+                                                 self.half, _stream(g)), "fa_half_buff_flush_mean")
 
     def fill(self, p: torch.Tensor, value: float, n: Optional[int] = None) -> None:
         """p[:n] = value as the 16-bit type holds it (zeros_like(...) + tau**2 on a 16-bit tensor,
         fedadam_aggregator.py:45-49)."""
-        ops.fill(p, self.round_scalar(value) if p.dtype == _F32 else value, n)
+        if p.dtype != self.dtype:
+            return ops.fill(p, value, n)
+        n = p.numel() if n is None else n
+        if n:
+            N.check(N.load().fa_half_fill(_dev(p, self.dtype), float(value), n, self.half, _stream(p)),
+                    "fa_half_fill")
 
 
 def for_layout(layout, base):

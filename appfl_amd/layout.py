@@ -9,11 +9,10 @@ The aggregation kernels work on flat vectors, one per arithmetic class:
 
 (classification: algorithm/aggregator/fedavg_aggregator.py:333-340 of the reference.)
 
-bfloat16 / float16 entries take the two fp32 classes: on the device they ride in fp32 CARRIERS
-(floats that only hold values of the 16-bit type; widening and narrowing are exact) and the
-kernels of :mod:`appfl_amd.half_ops` round every operation to the 16-bit type.  An entry's
-`dtype` is then the carrier's (float32), its `model_dtype` the 16-bit type the caller sees.  All
-entries of the two fp32 classes must share one type: a state dict that mixes fp32 with 16-bit
+bfloat16 / float16 entries take the two fp32 classes and stay 16 bits wide: in the rows and in
+the flat vector (still keyed ``"f32"``) their elements are 2 bytes, and the kernels of
+:mod:`appfl_amd.half_ops` round every operation to the 16-bit type.  All entries of the two
+classes must share one type (`Layout.float_dtype`): a state dict that mixes fp32 with 16-bit
 tensors (or the two 16-bit types) is refused.
 
 A client's state dict is packed into one ROW of bytes with the segments in that order::
@@ -58,11 +57,6 @@ class Entry:
     byte_offset: int   # byte offset inside a row
     src_offset: int = 0    # first element of the client's tensor this entry covers
     full_numel: int = -1   # elements of the client's whole tensor (-1: numel, the entry is whole)
-    model_dtype: Optional[torch.dtype] = None   # the caller's dtype when it is not `dtype` (16-bit floats)
-
-    @property
-    def caller_dtype(self) -> torch.dtype:
-        return self.model_dtype or self.dtype
 
 
 def classify(dtype: torch.dtype, is_parameter: bool) -> str:
@@ -98,9 +92,10 @@ class Layout:
                 f"a state dict that mixes {sorted(str(k) for k in kinds)} entries is not supported by "
                 "the MI355X aggregation kernels: fp32, bfloat16 and float16 tensors each need a state "
                 "dict of their own kind (float64 and integer entries may accompany any of them)")
-        kind = next(iter(kinds), torch.float32)
-        # the 16-bit type the fp32-class entries are rounded to (None: they are plain fp32)
-        self.half_dtype: Optional[torch.dtype] = kind if kind in HALF_DTYPES else None
+        # the type of the entries of the two fp32 classes: float32, or the 16-bit type of a
+        # bfloat16 / float16 model (`half_dtype` names it, None for fp32)
+        self.float_dtype: torch.dtype = next(iter(kinds), torch.float32)
+        self.half_dtype: Optional[torch.dtype] = self.float_dtype if self.float_dtype in HALF_DTYPES else None
         self.count = {c: sum(_numel(s) for _, s, _ in order[c]) for c in order}
         self.n_f32 = self.count[STEP] + self.count[MEAN_F32]
         self.n_f64 = self.count[STEP_F64] + self.count[MEAN_F64]
@@ -110,19 +105,25 @@ class Layout:
             off = 0
             for name, shape, dtype in order[c]:
                 n = _numel(shape)
-                by_name[name] = Entry(name, shape, _DTYPE[c], n, c, off,
-                                      self.seg_byte[c] + off * _ITEMSIZE[c],
-                                      model_dtype=dtype if dtype != _DTYPE[c] else None)
+                by_name[name] = Entry(name, shape, dtype, n, c, off,
+                                      self.seg_byte[c] + off * self.itemsize(c))
                 off += n
         # global-state (dict) order is the order the names were given in
         self.entries: List[Entry] = [by_name[n] for n, _, _ in names_shapes_dtypes]
         self.by_name = by_name
         self.names = [e.name for e in self.entries]
 
+    def itemsize(self, cls: str) -> int:
+        """Bytes per element of class `cls` in a row and in its flat vector."""
+        if cls in (STEP, MEAN_F32) and self.half_dtype is not None:
+            return 2
+        return _ITEMSIZE[cls]
+
     def _place_segments(self) -> None:
         """Byte offsets of the class segments inside a row, from `count` / `n_f32` / `n_f64`."""
-        self.seg_byte = {STEP: 0, MEAN_F32: 4 * self.count[STEP]}
-        self.seg_byte[STEP_F64] = _round_up(4 * self.n_f32, 16)
+        fsize = self.itemsize(STEP)
+        self.seg_byte = {STEP: 0, MEAN_F32: fsize * self.count[STEP]}
+        self.seg_byte[STEP_F64] = _round_up(fsize * self.n_f32, 16)
         self.seg_byte[MEAN_F64] = self.seg_byte[STEP_F64] + 8 * self.count[STEP_F64]
         self.seg_byte[MEAN_I64] = self.seg_byte[STEP_F64] + 8 * self.n_f64
         self.seg_byte[MEAN_I32] = self.seg_byte[MEAN_I64] + 8 * self.count[MEAN_I64]
@@ -133,7 +134,7 @@ class Layout:
         """Flat global-state vectors: 'f32' (step segment first, then mean_f32), 'f64' (same),
         'i64', 'i32'."""
         return {
-            "f32": torch.zeros(max(self.n_f32, 1), dtype=torch.float32, device=device),
+            "f32": torch.zeros(max(self.n_f32, 1), dtype=self.float_dtype, device=device),
             "f64": torch.zeros(max(self.n_f64, 1), dtype=torch.float64, device=device),
             "i64": torch.zeros(max(self.count[MEAN_I64], 1), dtype=torch.int64, device=device),
             "i32": torch.zeros(max(self.count[MEAN_I32], 1), dtype=torch.int32, device=device),
@@ -157,23 +158,14 @@ class Layout:
         return e.offset
 
     def view(self, flats: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
-        """The entry's stretch of its flat vector, writable (for a 16-bit entry: the fp32 carrier)."""
         e = self.by_name[name]
         off = self.flat_offset(e)
         return flats[self.flat_key(e.cls)][off:off + e.numel].view(e.shape)
 
-    def export(self, flats: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
-        """The entry as the caller sees it: `view`, narrowed to the 16-bit type (a copy) for a
-        16-bit entry."""
-        t = self.view(flats, name)
-        md = self.by_name[name].model_dtype
-        return t if md is None else t.to(md)
-
     def views(self, flats: Dict[str, torch.Tensor], classes: Optional[Iterable[str]] = None
               ) -> Dict[str, torch.Tensor]:
-        """{name: `export`} of every entry (of the given classes)."""
         keep = None if classes is None else set(classes)
-        return {e.name: self.export(flats, e.name) for e in self.entries
+        return {e.name: self.view(flats, e.name) for e in self.entries
                 if keep is None or e.cls in keep}
 
     def matches(self, state: Dict[str, torch.Tensor]) -> bool:
@@ -182,7 +174,7 @@ class Layout:
             return False
         for e in self.entries:
             t = state.get(e.name)
-            if t is None or tuple(t.shape) != e.shape or t.dtype != e.caller_dtype:
+            if t is None or tuple(t.shape) != e.shape or t.dtype != e.dtype:
                 return False
         return True
 
@@ -206,7 +198,7 @@ class WindowedLayout(Layout):
         if full.half_dtype is not None:
             raise NotImplementedError("bfloat16 / float16 state dicts are not supported by the sharded "
                                       "(multi-GPU) aggregator; there is no CPU fallback")
-        self.half_dtype = None
+        self.half_dtype, self.float_dtype = None, torch.float32
         self.full = full
         self.count = dict(full.count)
         self.count[STEP] = storage

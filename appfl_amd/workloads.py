@@ -100,6 +100,11 @@ def flat(n: int) -> List[Row]:
     return [("flat", (n,), torch.float32, True)]
 
 
+def as_dtype(rows: List[Row], dtype: torch.dtype) -> List[Row]:
+    """The same table with every fp32 tensor held in `dtype` (a model after `.to(dtype)`)."""
+    return [(n, shp, dtype if dt == torch.float32 else dt, p) for n, shp, dt, p in rows]
+
+
 def numel(rows: List[Row], params_only: bool = False) -> int:
     total = 0
     for _, shape, _, is_param in rows:
@@ -122,6 +127,9 @@ WORKLOADS: Dict[str, Dict] = {
     "resnet50_fedadam_k16": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 16},
     "resnet50_fedadam_k24": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 24},
     "resnet50_fedadam_k32": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 32},
+    # a bfloat16 model: rows and state stay 2 bytes per element, every operation is rounded to bfloat16
+    "resnet50_fedadam_k64_bf16": {"table": lambda: as_dtype(resnet(50), torch.bfloat16),
+                                  "cls": "FedAdamAggregator", "K": 64},
     "resnet50_fedavg_k64": {"table": lambda: resnet(50), "cls": "FedAvgAggregator", "K": 64},
     "resnet50_fedavgm_k64": {"table": lambda: resnet(50), "cls": "FedAvgMAggregator", "K": 64},
     "vitb16_fedasync": {"table": vit_b_16, "cls": "FedAsyncAggregator", "K": 1},

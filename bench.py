@@ -47,6 +47,7 @@ SHARDED_WORKLOAD = "flat1300m_fedavg_k32"
 NORTH_STAR_WORKLOAD = "resnet50_fedadam_k64"
 SHARDED_EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64"]
 EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "resnet50_fedavgm_k64",
+                   "resnet50_fedadam_k64_bf16",
                    "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
                    "vitb16_fedbuff_first", "vitb16_fedbuff_middle", "vitb16_fedbuff_flush",
                    "vitb16_fedcompass_group_k8", "vitb16_fedqueue_replace_k16"]
@@ -109,19 +110,35 @@ class SyncBench:
         self.agg._init_global_state(template_state(rows))
         lay = self.agg._layout
         self.n_step = lay.count[STEP]
-        self.payload = 4 * lay.n_f32 + 8 * lay.count[MEAN_I64] + 4 * lay.count[MEAN_I32]
+        half = lay.half_dtype      # a 16-bit model: 2-byte elements in the rows and in the state
+        item = 2 if half is not None else 4
+        self.payload = item * lay.n_f32 + 8 * lay.count[MEAN_I64] + 4 * lay.count[MEAN_I32]
         g = self.agg._flats["f32"]
-        ops.synth_fill(g, 7 + 1000003 * rank, scale=0.05, n=lay.n_f32)
         slab = self.agg._slab
         slab.reserve(self.K)
         slab.slab.zero_()
-        for k in range(self.K):
-            ops.synth_fill(slab.row_view(k, 0, lay.n_f32, torch.float32), 1000 + k + 1000003 * rank,
-                           scale=0.01, base=g, n=lay.n_f32)
+        if half is None:
+            ops.synth_fill(g, 7 + 1000003 * rank, scale=0.05, n=lay.n_f32)
+            for k in range(self.K):
+                ops.synth_fill(slab.row_view(k, 0, lay.n_f32, torch.float32), 1000 + k + 1000003 * rank,
+                               scale=0.01, base=g, n=lay.n_f32)
+        else:
+            # the same synthetic values, generated in fp32 and rounded to the 16-bit type
+            g32, x32 = (torch.empty(lay.n_f32, dtype=torch.float32, device=g.device) for _ in range(2))
+            ops.synth_fill(g32, 7 + 1000003 * rank, scale=0.05, n=lay.n_f32)
+            g[:lay.n_f32].copy_(g32)
+            g32.copy_(g[:lay.n_f32])
+            for k in range(self.K):
+                ops.synth_fill(x32, 1000 + k + 1000003 * rank, scale=0.01, base=g32, n=lay.n_f32)
+                slab.row_view(k, 0, lay.n_f32, half).copy_(x32)
+            del g32, x32
         self.weights = [1.0 / self.K] * self.K
         self.opt = self.agg._OPT
-        self.kernel = "%s<%s>" % (ops.reduce_kernel_name(self.K, self.n_step, self.opt), self.opt)
-        self.alg_bytes = 4 * (self.K + STATE_VECTORS[self.opt]) * self.n_step
+        if half is None:
+            self.kernel = "%s<%s>" % (ops.reduce_kernel_name(self.K, self.n_step, self.opt), self.opt)
+        else:
+            self.kernel = "reduce_half_kernel<%s,%s>" % (self.opt, str(half).split(".")[-1])
+        self.alg_bytes = item * (self.K + STATE_VECTORS[self.opt]) * self.n_step
         self.client_bytes = self.K * self.payload
         self.result_numel = lay.n_f32
         self.sets, self.turn = [], 0

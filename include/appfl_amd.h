@@ -387,41 +387,43 @@ int fa_fill_f64(double* p, double value, size_t n, fa_stream_t stream);
  * the same names).  On 16-bit float tensors PyTorch's CPU kernels evaluate each tensor operation
  * in fp32 and round its result to the tensor's type (nearest even); a Python scalar that
  * multiplies / divides enters as its fp32 value, one that is added (tau, tau**2) or passed as
- * `alpha=` of add_ / sub_ is rounded to the tensor's type first.  The buffers here are fp32
- * CARRIERS: floats that only hold values representable in the 16-bit type `half` names (widening
- * a 16-bit tensor into one and narrowing it back are exact); every operation's result is rounded
- * to that type on the device, so the carriers leave holding exactly the reference's values.
+ * `alpha=` of add_ / sub_ is rounded to the tensor's type first.  EVERY buffer here -- client
+ * rows, g, m, v, steps, workspaces -- holds 16-bit elements of the type `half` names (n counts
+ * elements); the kernels widen on load, round every operation's result to that type on the
+ * device and narrow on store, so the buffers leave holding exactly the reference's values.
  * w, alpha_t, lr, beta* enter as (float) of the double; tau as that float rounded to the type.
- * Buffers must be 4-byte aligned (16-byte aligned buffers take 128-bit loads).
+ * Buffers must be 2-byte aligned (16-byte aligned buffers take 128-bit loads of 8 elements).
  */
 enum fa_half {
     FA_HALF_BF16 = 1,   /* torch.bfloat16 */
     FA_HALF_F16 = 2     /* torch.float16  */
 };
-/* (float)x rounded to the 16-bit type, as a float: how tau**2 lands in v's initial value
- * (fedadam_aggregator.py:45-49, zeros_like(...) + tau**2 on a 16-bit tensor). */
+/* (float)x rounded to the 16-bit type, as a float (how PyTorch lands a Python scalar in a 16-bit
+ * tensor: zeros_like(...) + tau**2, fedadam_aggregator.py:45-49). */
 float fa_half_round_scalar(double x, int half);
-int fa_half_reduce_opt(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+int fa_half_reduce_opt(const void* const* x, const double* w, int K, void* g, void* m, void* v,
                        size_t n, int opt, double lr, double beta1, double beta2, double tau,
-                       float* step_out, float* step_ws, int half, fa_stream_t stream);
-int fa_half_reduce_step(const float* const* x, const double* w, int K, const float* g, float* step_out,
+                       void* step_out, void* step_ws, int half, fa_stream_t stream);
+int fa_half_reduce_step(const void* const* x, const double* w, int K, const void* g, void* step_out,
                         size_t n, int half, fa_stream_t stream);
-int fa_half_server_opt_step(float* step, float* m, float* v, size_t n, int opt, double lr, double beta1,
+int fa_half_server_opt_step(void* step, void* m, void* v, size_t n, int opt, double lr, double beta1,
                             double beta2, double tau, int half, fa_stream_t stream);
-int fa_half_apply_step(float* g, const float* step, size_t n, int half, fa_stream_t stream);
-int fa_half_mean(const float* const* x, int K, float* g, size_t n, int half, fa_stream_t stream);
+int fa_half_apply_step(void* g, const void* step, size_t n, int half, fa_stream_t stream);
+int fa_half_mean(const void* const* x, int K, void* g, size_t n, int half, fa_stream_t stream);
 /* sub_form != 0 is the reference's optimize_memory branch (fedasync_aggregator.py:243-258), where
  * alpha_t is the `alpha=` of add_ / sub_ and is therefore rounded to the 16-bit type -- for the
  * model-based step too; sub_form == 0 (:260-264) multiplies by the fp32 alpha_t. */
-int fa_half_async_mix(const float* x, double alpha_t, int gradient_based, int sub_form, float* g,
-                      float* step_out, size_t n, int half, fa_stream_t stream);
+int fa_half_async_mix(const void* x, double alpha_t, int gradient_based, int sub_form, void* g,
+                      void* step_out, size_t n, int half, fa_stream_t stream);
 /* fedbuff_aggregator.py:145-158 (and, with flush != 0, :75-88 for the weighted entries). */
-int fa_half_buff_accum(const float* x, double alpha_t, int gradient_based, float* g, float* step,
+int fa_half_buff_accum(const void* x, double alpha_t, int gradient_based, void* g, void* step,
                        int first, int flush, size_t n, int half, fa_stream_t stream);
-int fa_half_buff_accum_raw(const float* x, float* step, int first, size_t n, int half,
+int fa_half_buff_accum_raw(const void* x, void* step, int first, size_t n, int half,
                            fa_stream_t stream);
-int fa_half_buff_flush_mean(float* g, const float* step, int K, size_t n, int half,
+int fa_half_buff_flush_mean(void* g, const void* step, int K, size_t n, int half,
                             fa_stream_t stream);
+/* p[i] = fa_half_round_scalar(value): moment initialisation of a 16-bit model. */
+int fa_half_fill(void* p, double value, size_t n, int half, fa_stream_t stream);
 
 /* p[i] = value: moment initialisation (m = 0, v = (float)(tau**2), fedadam_aggregator.py:45-49). */
 int fa_fill_f32(float* p, float value, size_t n, fa_stream_t stream);

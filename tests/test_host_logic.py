@@ -127,17 +127,20 @@ def test_layout_classes_offsets_and_rows():
     assert nomodel.count[L.MEAN_F32] == 0
     with pytest.raises(NotImplementedError):
         L.Layout([("h", (3,), torch.int8)], None)
-    # 16-bit floats ride in fp32 carriers: same offsets as the fp32 layout, the caller's dtype kept
-    # beside the carrier's; a state dict that mixes float kinds is refused
+    # 16-bit floats stay 2 bytes wide: same classes and element offsets as the fp32 layout, half the
+    # bytes in a row, a 16-bit flat vector; a state dict that mixes float kinds is refused
     half = L.Layout([(n, tuple(t.shape), torch.bfloat16 if t.dtype == torch.float32 else t.dtype)
                      for n, t in state.items()], named)
-    assert half.half_dtype == torch.bfloat16 and lay.half_dtype is None
-    assert [(e.name, e.cls, e.byte_offset) for e in half.entries] == [(e.name, e.cls, e.byte_offset) for e in lay.entries]
+    assert half.half_dtype == half.float_dtype == torch.bfloat16
+    assert lay.half_dtype is None and lay.float_dtype == torch.float32
+    assert [(e.name, e.cls, e.offset) for e in half.entries] == [(e.name, e.cls, e.offset) for e in lay.entries]
+    assert half.seg_byte[L.MEAN_F32] == 2 * half.count[L.STEP] and half.seg_byte[L.MEAN_I64] % 16 == 0
+    assert half.row_bytes % 256 == 0 and half.row_bytes < lay.row_bytes
     e = half.by_name["fc.weight"]
-    assert e.dtype == torch.float32 and e.model_dtype == torch.bfloat16 and e.caller_dtype == torch.bfloat16
-    assert half.by_name["bn.num_batches_tracked"].model_dtype is None
-    hv = half.views(flats)
-    assert hv["fc.weight"].dtype == torch.bfloat16 and half.view(flats, "fc.weight").dtype == torch.float32
+    assert e.dtype == torch.bfloat16 and e.byte_offset == 2 * e.offset
+    hflats = half.alloc_state("cpu")
+    assert hflats["f32"].dtype == torch.bfloat16 and hflats["i64"].dtype == torch.int64
+    assert half.views(hflats)["fc.weight"].dtype == torch.bfloat16
     assert half.matches({n: (t.to(torch.bfloat16) if t.dtype == torch.float32 else t) for n, t in state.items()})
     assert not half.matches(state) and lay.matches(state)
     for kinds in ((torch.float32, torch.bfloat16), (torch.float16, torch.bfloat16)):
