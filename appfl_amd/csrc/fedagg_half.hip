@@ -29,6 +29,28 @@ constexpr int kMaxBlocks = 1 << 20;
 constexpr int kAhead = 8;   // client loads in flight per element / vector
 constexpr int kWide = 8;    // elements of a 128-bit load
 
+// Launch shape of the 128-bit reduce kernel: vectors per thread and client loads in flight per
+// vector (build-time knobs for A/B runs; the defaults are the measured best).  ResNet-50 x 64
+// clients, FedAdam, bfloat16, kernel time: 1 x 8 0.623 ms, 2 x 8 / 2 x 4 0.637, 4 x 4 0.631,
+// 1 x 16 0.639 (2 x 16 and 4 x 8 spill); streaming loads of m / v 1.5 % slower; write-through
+// result stores 10 % slower; XCD runs of 32 or 128 tiles 0.7 % faster; with every rounding
+// compiled out 0.611 ms -- the roundings are not what bounds it.
+#ifndef FA_HALF_VPT
+#define FA_HALF_VPT 1
+#endif
+#ifndef FA_HALF_AHEAD
+#define FA_HALF_AHEAD 8
+#endif
+#ifndef FA_HALF_NT_STATE
+#define FA_HALF_NT_STATE 0
+#endif
+#ifndef FA_HALF_XCD_RUN
+#define FA_HALF_XCD_RUN 32     // > 0: inside windows of 8 * RUN tiles each XCD takes RUN consecutive tiles
+#endif
+#ifndef FA_HALF_WT
+#define FA_HALF_WT 0           // 1: results leave with write-through stores
+#endif
+
 template <int HALF> struct Elem;
 template <> struct Elem<FA_HALF_BF16> { typedef __bf16 T; };
 template <> struct Elem<FA_HALF_F16> { typedef _Float16 T; };
@@ -43,8 +65,22 @@ template <> struct Elem<FA_HALF_F16> { typedef _Float16 T; };
 // 4 % of the products m * 0.9f came out one unit in the last place apart.
 template <int HALF>
 __device__ __forceinline__ float rnd(float x) {
-    __asm__("" : "+v"(x));
-    return static_cast<float>(static_cast<typename Elem<HALF>::T>(x));
+#ifdef FA_HALF_DEBUG_NO_ROUNDING      // timing experiment only: wrong results
+    return x;
+#endif
+    if constexpr (HALF == FA_HALF_BF16) {
+        // The packed conversion of the pair (0, x) leaves x's bfloat16 in the HIGH half of the
+        // dword and zero below it -- which is the rounded value as an fp32 already: one
+        // instruction per rounding instead of a conversion and a shift (no instruction fuses a
+        // multiply with a conversion to bfloat16, so nothing needs hiding from the compiler here).
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        const f2 pair = {0.0f, x};
+        return __builtin_bit_cast(float, __builtin_convertvector(pair, b2));
+    } else {
+        __asm__("" : "+v"(x));
+        return static_cast<float>(static_cast<_Float16>(x));
+    }
 }
 
 template <int HALF>
@@ -130,6 +166,24 @@ __device__ __forceinline__ void store_h(void* p, size_t i, const PackH<VEC>& r) 
     }
 }
 
+// Result store of the 128-bit kernels: optionally write-through (sc0 sc1), which keeps result
+// lines from lingering dirty in L2 between the streaming reads.
+template <int HALF, int VEC>
+__device__ __forceinline__ void store_result_h(void* p, size_t i, const PackH<VEC>& r) {
+    if constexpr (VEC == kWide && FA_HALF_WT != 0) {
+        u4 t;
+        t.x = narrow2<HALF>(r.e[0], r.e[1]);
+        t.y = narrow2<HALF>(r.e[2], r.e[3]);
+        t.z = narrow2<HALF>(r.e[4], r.e[5]);
+        t.w = narrow2<HALF>(r.e[6], r.e[7]);
+        u4* q = static_cast<u4*>(p) + i;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(q, 0, 16, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, 0, 0, 17);
+    } else {
+        store_h<HALF, VEC>(p, i, r);
+    }
+}
+
 template <int HALF>
 __device__ __forceinline__ float ld(const void* p, size_t i) { return load_h<HALF, 1, false>(p, i).e[0]; }
 template <int HALF>
@@ -191,68 +245,100 @@ struct ReduceHArgs {
     HyperH h;
 };
 
-template <int OPT, int HALF, int VEC>
+// One block walks tiles of kThreads * VPT elements of width VEC; thread t owns elements
+// t, t + kThreads, ... of the tile, so every load instruction of a wave covers one contiguous KiB.
+template <int OPT, int HALF, int VEC, int VPT, int U>
 __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs a) {
-    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.n; i += stride) {
-        const PackH<VEC> g = load_h<HALF, VEC, false>(a.apply ? a.g : a.g_ro, i);
-        PackH<VEC> s;
-        if (a.step_in) {
-            s = load_h<HALF, VEC, false>(a.step_in, i);
-        } else {
+    constexpr bool NTS = FA_HALF_NT_STATE != 0;
+    const size_t tile_elems = static_cast<size_t>(kThreads) * VPT;
+    const size_t tiles = (a.n + tile_elems - 1) / tile_elems;
+    for (size_t t0 = blockIdx.x; t0 < tiles; t0 += gridDim.x) {
+        size_t tile = t0;
+        if constexpr (FA_HALF_XCD_RUN > 0 && VEC == kWide) {
+            // blocks are dispatched round-robin over the 8 XCDs: give each XCD runs of consecutive tiles
+            constexpr size_t R = FA_HALF_XCD_RUN;
+            const size_t win = t0 & ~(8 * R - 1);
+            if (win + 8 * R <= tiles) tile = win + (t0 & 7) * R + ((t0 >> 3) & (R - 1));
+        }
+        size_t idx[VPT], at_[VPT];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) s.e[e] = 0.0f;
+        for (int q = 0; q < VPT; ++q) {
+            idx[q] = tile * tile_elems + static_cast<size_t>(q) * kThreads + threadIdx.x;
+            at_[q] = idx[q] < a.n ? idx[q] : a.n - 1;      // loads of a ragged last tile stay in bounds
+        }
+        PackH<VEC> g[VPT], s[VPT];
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+            g[q] = load_h<HALF, VEC, false>(a.apply ? a.g : a.g_ro, at_[q]);
+            if (a.step_in) {
+                s[q] = load_h<HALF, VEC, false>(a.step_in, at_[q]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s[q].e[e] = 0.0f;
+            }
         }
         int k = 0;
-        for (; k + kAhead <= a.K; k += kAhead) {
-            PackH<VEC> x[kAhead];
+        for (; k + U <= a.K; k += U) {
+            PackH<VEC> x[U][VPT];
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) x[u] = load_h<HALF, VEC, true>(a.x[k + u], i);
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int u = 0; u < kAhead; ++u) {
+                for (int q = 0; q < VPT; ++q) x[u][q] = load_h<HALF, VEC, true>(a.x[k + u], at_[q]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
                 const float w = a.w[k + u];
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    float d = rnd<HALF>(x[u].e[e] - g.e[e]);
-                    float wd = rnd<HALF>(d * w);
-                    s.e[e] = rnd<HALF>(s.e[e] + wd);
-                }
+                for (int q = 0; q < VPT; ++q)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float d = rnd<HALF>(x[u][q].e[e] - g[q].e[e]);
+                        float wd = rnd<HALF>(d * w);
+                        s[q].e[e] = rnd<HALF>(s[q].e[e] + wd);
+                    }
             }
         }
         for (; k < a.K; ++k) {
-            const PackH<VEC> x = load_h<HALF, VEC, true>(a.x[k], i);
             const float w = a.w[k];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float d = rnd<HALF>(x.e[e] - g.e[e]);
-                float wd = rnd<HALF>(d * w);
-                s.e[e] = rnd<HALF>(s.e[e] + wd);
+            for (int q = 0; q < VPT; ++q) {
+                const PackH<VEC> x = load_h<HALF, VEC, true>(a.x[k], at_[q]);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float d = rnd<HALF>(x.e[e] - g[q].e[e]);
+                    float wd = rnd<HALF>(d * w);
+                    s[q].e[e] = rnd<HALF>(s[q].e[e] + wd);
+                }
             }
         }
-        if (!a.last) {
-            store_h<HALF, VEC>(a.step_out, i, s);
-            continue;
-        }
-        if (OPT != FA_OPT_NONE) {
-            PackH<VEC> v = load_h<HALF, VEC, false>(a.v, i);
-            PackH<VEC> m;
-            if (OPT != FA_OPT_AVGM) {
-                m = load_h<HALF, VEC, false>(a.m, i);
-            } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) m.e[e] = 0.0f;
+        for (int q = 0; q < VPT; ++q) {
+            if (idx[q] >= a.n) continue;
+            const size_t i = idx[q];
+            if (!a.last) {
+                store_h<HALF, VEC>(a.step_out, i, s[q]);
+                continue;
             }
+            if (OPT != FA_OPT_NONE) {
+                PackH<VEC> v = load_h<HALF, VEC, NTS>(a.v, i);
+                PackH<VEC> m;
+                if (OPT != FA_OPT_AVGM) {
+                    m = load_h<HALF, VEC, NTS>(a.m, i);
+                } else {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) s.e[e] = optimizer_step_h<OPT, HALF>(s.e[e], m.e[e], v.e[e], a.h);
-            store_h<HALF, VEC>(a.v, i, v);
-            if (OPT != FA_OPT_AVGM) store_h<HALF, VEC>(a.m, i, m);
-        }
-        if (a.step_out) store_h<HALF, VEC>(a.step_out, i, s);
-        if (a.apply) {
-            PackH<VEC> r;
+                    for (int e = 0; e < VEC; ++e) m.e[e] = 0.0f;
+                }
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) r.e[e] = rnd<HALF>(g.e[e] + s.e[e]);
-            store_h<HALF, VEC>(a.g, i, r);
+                for (int e = 0; e < VEC; ++e) s[q].e[e] = optimizer_step_h<OPT, HALF>(s[q].e[e], m.e[e], v.e[e], a.h);
+                store_result_h<HALF, VEC>(a.v, i, v);
+                if (OPT != FA_OPT_AVGM) store_result_h<HALF, VEC>(a.m, i, m);
+            }
+            if (a.step_out) store_result_h<HALF, VEC>(a.step_out, i, s[q]);
+            if (a.apply) {
+                PackH<VEC> r;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r.e[e] = rnd<HALF>(g[q].e[e] + s[q].e[e]);
+                store_result_h<HALF, VEC>(a.g, i, r);
+            }
         }
     }
 }
@@ -384,13 +470,16 @@ HyperH make_hyper_h(double lr, double beta1, double beta2, double tau, int half)
 
 template <int HALF, int VEC>
 void launch_reduce_half(int opt, const ReduceHArgs& a, hipStream_t st) {
-    const dim3 grid(grid_for(a.n)), block(kThreads);
+    constexpr int VPT = VEC == kWide ? FA_HALF_VPT : 1;
+    constexpr int U = VEC == kWide ? FA_HALF_AHEAD : kAhead;
+    const size_t tiles = (a.n + static_cast<size_t>(kThreads) * VPT - 1) / (static_cast<size_t>(kThreads) * VPT);
+    const dim3 grid(static_cast<unsigned>(tiles > static_cast<size_t>(kMaxBlocks) ? kMaxBlocks : tiles)), block(kThreads);
     switch (opt) {
-        case FA_OPT_NONE: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_NONE, HALF, VEC>), grid, block, 0, st, a); break;
-        case FA_OPT_AVGM: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_AVGM, HALF, VEC>), grid, block, 0, st, a); break;
-        case FA_OPT_ADAM: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_ADAM, HALF, VEC>), grid, block, 0, st, a); break;
-        case FA_OPT_YOGI: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_YOGI, HALF, VEC>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_ADAGRAD, HALF, VEC>), grid, block, 0, st, a); break;
+        case FA_OPT_NONE: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_NONE, HALF, VEC, VPT, U>), grid, block, 0, st, a); break;
+        case FA_OPT_AVGM: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_AVGM, HALF, VEC, VPT, U>), grid, block, 0, st, a); break;
+        case FA_OPT_ADAM: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_ADAM, HALF, VEC, VPT, U>), grid, block, 0, st, a); break;
+        case FA_OPT_YOGI: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_YOGI, HALF, VEC, VPT, U>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((reduce_half_kernel<FA_OPT_ADAGRAD, HALF, VEC, VPT, U>), grid, block, 0, st, a); break;
     }
 }
 
