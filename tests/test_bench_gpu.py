@@ -61,7 +61,7 @@ def test_one_gpu_line_lists_every_benchmark_configuration():
     assert out["config"]["workload"] == "resnet18_fedavg_k100" and out["scaling"] == "weak"
     names = [w["workload"] for w in out["workloads"]]
     assert names == ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "resnet50_fedavgm_k64",
-                     "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
+                     "resnet50_fedadam_k64_bf16", "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
                      "vitb16_fedbuff_first", "vitb16_fedbuff_middle", "vitb16_fedbuff_flush",
                      "vitb16_fedcompass_group_k8", "vitb16_fedqueue_replace_k16"]
     by_name = {w["workload"]: w for w in out["workloads"]}
@@ -73,6 +73,10 @@ def test_one_gpu_line_lists_every_benchmark_configuration():
             for k in ("first", "middle", "flush")] == [12, 16, 20]
     assert by_name["vitb16_fedcompass_group_k8"]["algorithmic_bytes_per_launch"] == 4 * (8 + 2) * n_vit
     assert by_name["vitb16_fedqueue_replace_k16"]["algorithmic_bytes_per_launch"] == 4 * (16 + 1) * n_vit
+    # the bfloat16 model moves 2-byte elements: half the algorithmic bytes of the fp32 one
+    assert by_name["resnet50_fedadam_k64_bf16"]["algorithmic_bytes_per_launch"] * 2 == \
+        by_name["resnet50_fedadam_k64"]["algorithmic_bytes_per_launch"]
+    assert by_name["resnet50_fedadam_k64_bf16"]["kernel"] == "reduce_half_kernel<adam,bfloat16>"
     assert out["north_star_target"]["workload"] == "resnet50_fedadam_k64"
     assert out["north_star_target"]["frac"] == out["workloads"][0]["frac"]
     # cold-state figures (state vectors rotated over independent sets) beside the warm ones
