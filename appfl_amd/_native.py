@@ -90,6 +90,7 @@ SIGNATURES = {
     "fa_half_server_opt_step": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _i, _p]),
     "fa_half_apply_step": (_i, [_p, _p, _sz, _i, _p]),
     "fa_half_mean": (_i, [_p, _i, _p, _sz, _i, _p]),
+    "fa_half_weighted_mix": (_i, [_p, _p, _i, _p, _d, _i, _p, _sz, _i, _p]),
     "fa_half_async_mix": (_i, [_p, _d, _i, _i, _p, _p, _sz, _i, _p]),
     "fa_half_buff_accum": (_i, [_p, _d, _i, _p, _p, _i, _i, _sz, _i, _p]),
     "fa_half_buff_accum_raw": (_i, [_p, _p, _i, _sz, _i, _p]),

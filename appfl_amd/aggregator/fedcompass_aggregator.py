@@ -20,7 +20,7 @@ from typing import Any, Dict, Optional, OrderedDict, Union
 
 import torch
 
-from .. import ops
+from .. import half_ops, ops
 from ..layout import MEAN_F32, MEAN_F64, MEAN_I32, MEAN_I64, STEP, STEP_F64, Layout
 from ..staging import ClientSlab, HostDownloader
 from .base_aggregator import BaseAggregator, DeviceStateMixin, cfg_get, resolve_device
@@ -82,16 +82,12 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
             init = dict(first_model)
         self._layout = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()],
                               self.named_parameters)
-        if self._layout.half_dtype is not None:
-            self._layout = None
-            raise NotImplementedError(
-                "FedCompass / FedQueue on bfloat16 / float16 state dicts are not supported by the MI355X "
-                "aggregation kernels (fp32 and fp64 are); there is no CPU fallback")
         self._flats = self._layout.alloc_state(self.device)
         with torch.no_grad():
             for n, t in init.items():
                 self._layout.view(self._flats, n).copy_(t.detach())
         self._slab = ClientSlab(self._layout, self.device)
+        self._ops = half_ops.for_layout(self._layout, ops)      # 16-bit models: the rounding kernels
 
     def _stage(self, models) -> int:
         K = len(models)
@@ -113,23 +109,23 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
         """The weighted entries: fp32 and float64 segments take the same mix (for float64 tensors
         PyTorch keeps the Python scalars in double, and so does the f64 kernel)."""
         lay = self._layout
-        for cls, key, dtype, ws_attr in ((STEP, "f32", torch.float32, "_acc_ws"),
+        for cls, key, dtype, ws_attr in ((STEP, "f32", lay.float_dtype, "_acc_ws"),
                                          (STEP_F64, "f64", torch.float64, "_acc_ws64")):
             n = lay.count[cls]
             if not n:
                 continue
             ws = None
-            if K > ops.kchunk() and mode != "subtract":
+            if K > self._ops.kchunk() and mode != "subtract":
                 if getattr(self, ws_attr) is None:
                     setattr(self, ws_attr, torch.empty(n, dtype=dtype, device=self.device))
                 ws = getattr(self, ws_attr)
-            ops.weighted_mix(self._rows(K, lay.seg_byte[cls]), weights, self._flats[key], mode, coeff,
+            self._ops.weighted_mix(self._rows(K, lay.seg_byte[cls]), weights, self._flats[key], mode, coeff,
                              acc_ws=ws, n=n)
 
     def _non_step_segments(self):
         """(class, flat key, dtype, offset in the flat vector) of the entries that bypass the mix."""
         lay = self._layout
-        return ((MEAN_F32, "f32", torch.float32, lay.count[STEP]),
+        return ((MEAN_F32, "f32", lay.float_dtype, lay.count[STEP]),
                 (MEAN_F64, "f64", torch.float64, lay.count[STEP_F64]),
                 (MEAN_I64, "i64", torch.int64, 0), (MEAN_I32, "i32", torch.int32, 0))
 
@@ -137,7 +133,7 @@ class _MixAggregator(BaseAggregator, DeviceStateMixin):
         lay = self._layout
         for cls, key, _, lo in self._non_step_segments():
             if lay.count[cls]:
-                ops.mean(self._rows(K, lay.seg_byte[cls]), self._flats[key][lo:], n=lay.count[cls])
+                self._ops.mean(self._rows(K, lay.seg_byte[cls]), self._flats[key][lo:], n=lay.count[cls])
 
     def _replace_non_step(self) -> None:
         lay = self._layout

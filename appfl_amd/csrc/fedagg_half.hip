@@ -425,6 +425,80 @@ __global__ __launch_bounds__(kThreads) void arrival_half_kernel(const void* x, f
     }
 }
 
+// Weighted mixes of K client vectors that do not subtract g first (FedCompass / FedQueue,
+// fedcompass_aggregator.py:152-338, fedqueue_aggregator.py:75-131): the six combine modes of the
+// fp32 mix_kernel with every operation rounded.
+struct MixHArgs {
+    const void* x[FA_KCHUNK];
+    float w[FA_KCHUNK];
+    void* g;
+    const void* acc_in;   // partial sum of earlier client chunks (NULL: 0)
+    void* acc_out;        // where a non-final chunk leaves its partial sum
+    size_t n;             // elements of width VEC
+    int K, mode, last;
+    float coeff;
+};
+
+template <int HALF, int VEC>
+__global__ __launch_bounds__(kThreads) void mix_half_kernel(const MixHArgs a) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < a.n; i += stride) {
+        PackH<VEC> g, acc;
+        const bool reads_g = a.mode != FA_MIX_REPLACE && a.mode != FA_MIX_SUM_SET;
+        if (reads_g) {
+            g = load_h<HALF, VEC, false>(a.g, i);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) g.e[e] = 0.0f;
+        }
+        if (a.mode == FA_MIX_SUBTRACT) {
+            acc = g;
+        } else if (a.acc_in) {
+            acc = load_h<HALF, VEC, false>(a.acc_in, i);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.e[e] = (a.mode >= FA_MIX_CONVEX_ONE) ? -0.0f : 0.0f;   // -0 + y == y for every y
+        }
+        int k = 0;
+        for (; k + kAhead <= a.K; k += kAhead) {
+            PackH<VEC> x[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) x[u] = load_h<HALF, VEC, true>(a.x[k + u], i);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float xw = rnd<HALF>(x[u].e[e] * a.w[k + u]);
+                    acc.e[e] = rnd<HALF>((a.mode == FA_MIX_SUBTRACT) ? acc.e[e] - xw : acc.e[e] + xw);
+                }
+        }
+        for (; k < a.K; ++k) {
+            const PackH<VEC> x = load_h<HALF, VEC, true>(a.x[k], i);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float xw = rnd<HALF>(x.e[e] * a.w[k]);
+                acc.e[e] = rnd<HALF>((a.mode == FA_MIX_SUBTRACT) ? acc.e[e] - xw : acc.e[e] + xw);
+            }
+        }
+        if (!a.last && a.mode != FA_MIX_SUBTRACT) {
+            store_h<HALF, VEC>(a.acc_out, i, acc);
+            continue;
+        }
+        if ((a.mode == FA_MIX_CONVEX || a.mode == FA_MIX_CONVEX_ONE) && a.last) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float gt = rnd<HALF>(g.e[e] * a.coeff);
+                acc.e[e] = rnd<HALF>(gt + acc.e[e]);
+            }
+        }
+        if (a.mode == FA_MIX_SUM_ADD && a.last) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc.e[e] = rnd<HALF>(g.e[e] + acc.e[e]);
+        }
+        store_h<HALF, VEC>(a.g, i, acc);
+    }
+}
+
 template <int HALF>
 __global__ __launch_bounds__(kThreads) void accum_raw_half_kernel(const void* x, void* step, int first, size_t n) {
     const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
@@ -654,6 +728,60 @@ int fa_half_mean(const void* const* x, int K, void* g, size_t n, int half, fa_st
             hipLaunchKernelGGL((mean_half_kernel<FA_HALF_F16>), grid, block, 0, as_stream(stream), a);
         int rc = launch_status();
         if (rc != FA_OK) return rc;
+    }
+    return FA_OK;
+}
+
+int fa_half_weighted_mix(const void* const* x, const double* w, int K, void* g, double coeff, int mode,
+                         void* acc_ws, size_t n, int half, fa_stream_t stream) {
+    if (!x || !w || !g || K <= 0 || !known(half)) return FA_ERR_INVALID;
+    if (mode < FA_MIX_REPLACE || mode > FA_MIX_SUM_SET) return FA_ERR_INVALID;
+    if (mode == FA_MIX_CONVEX_ONE && K != 1) return FA_ERR_INVALID;
+    if (K > FA_KCHUNK && mode != FA_MIX_SUBTRACT && !acc_ws) return FA_ERR_WORKSPACE;
+    if (!aligned2(g) || (acc_ws && !aligned2(acc_ws))) return FA_ERR_ALIGN;
+    bool wide = aligned16(g) && (!acc_ws || aligned16(acc_ws));
+    for (int k = 0; k < K; ++k) {
+        if (!x[k]) return FA_ERR_INVALID;
+        if (!aligned2(x[k])) return FA_ERR_ALIGN;
+        wide = wide && aligned16(x[k]);
+    }
+    if (n == 0) return FA_OK;
+    const size_t body = wide ? n / kWide * kWide : 0;
+    const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
+    for (int ch = 0; ch < chunks; ++ch) {
+        MixHArgs a;
+        memset(&a, 0, sizeof(a));
+        const int k0 = ch * FA_KCHUNK;
+        a.K = (K - k0 < FA_KCHUNK) ? K - k0 : FA_KCHUNK;
+        a.mode = mode;
+        a.last = (ch == chunks - 1);
+        a.coeff = static_cast<float>(coeff);
+        for (int part = 0; part < 2; ++part) {
+            const size_t lo = part ? body : 0, cnt = part ? n - body : body;
+            if (cnt == 0) continue;
+            for (int k = 0; k < a.K; ++k) {
+                a.x[k] = at(x[k0 + k], lo);
+                a.w[k] = static_cast<float>(w[k0 + k]);
+            }
+            a.g = at(g, lo);
+            a.acc_in = (ch == 0 || mode == FA_MIX_SUBTRACT) ? nullptr : at(static_cast<const void*>(acc_ws), lo);
+            a.acc_out = at(acc_ws, lo);
+            a.n = part ? cnt : cnt / kWide;
+            const dim3 grid(grid_for(a.n)), block(kThreads);
+            if (part == 0) {
+                if (half == FA_HALF_BF16)
+                    hipLaunchKernelGGL((mix_half_kernel<FA_HALF_BF16, kWide>), grid, block, 0, as_stream(stream), a);
+                else
+                    hipLaunchKernelGGL((mix_half_kernel<FA_HALF_F16, kWide>), grid, block, 0, as_stream(stream), a);
+            } else {
+                if (half == FA_HALF_BF16)
+                    hipLaunchKernelGGL((mix_half_kernel<FA_HALF_BF16, 1>), grid, block, 0, as_stream(stream), a);
+                else
+                    hipLaunchKernelGGL((mix_half_kernel<FA_HALF_F16, 1>), grid, block, 0, as_stream(stream), a);
+            }
+            int rc = launch_status();
+            if (rc != FA_OK) return rc;
+        }
     }
     return FA_OK;
 }

@@ -98,10 +98,17 @@ class HalfOps:
         N.check(N.load().fa_half_mean(_check_rows(x, n, self.dtype), len(x), _dev(g, self.dtype), n,
                                       self.half, _stream(g)), "fa_half_mean")
 
-    def weighted_mix(self, *args, **kwargs):
-        raise NotImplementedError(
-            "FedCompass / FedQueue mixes and secure-aggregation payloads on bfloat16 / float16 "
-            "state dicts are not supported by the MI355X aggregation kernels; there is no CPU fallback")
+    def weighted_mix(self, x: Sequence, w: Sequence[float], g: torch.Tensor, mode: str, coeff: float = 0.0,
+                     acc_ws: Optional[torch.Tensor] = None, n: Optional[int] = None) -> None:
+        if g.dtype != self.dtype:
+            return ops.weighted_mix(x, w, g, mode, coeff, acc_ws, n)
+        n = g.numel() if n is None else n
+        if len(x) != len(w):
+            raise ValueError("one weight per client buffer")
+        rc = N.load().fa_half_weighted_mix(
+            _check_rows(x, n, self.dtype), N.double_array([float(t) for t in w]), len(x), _dev(g, self.dtype),
+            float(coeff), ops.MIX_MODES[mode], _dev(acc_ws, self.dtype), n, self.half, _stream(g))
+        N.check(rc, "fa_half_weighted_mix")
 
     def async_mix(self, x, alpha_t: float, g, gradient_based: bool = False, sub_form: bool = True,
                   step_out=None, n: Optional[int] = None) -> None:

@@ -410,7 +410,8 @@ def end_to_end(wl, rounds=4, arrivals=7):
     from appfl_amd import ops, workloads as W
 
     rows, K = wl["table"](), wl["K"]
-    nf = W.numel([r for r in rows if r[2] == torch.float32])
+    floats = (torch.float32, torch.bfloat16, torch.float16)     # a 16-bit model: the same values, rounded
+    nf = W.numel([r for r in rows if r[2] in floats])
     base = torch.empty(nf, dtype=torch.float32, device="cuda")
     ops.synth_fill(base, 7, scale=0.05)
     buf = torch.empty_like(base)
@@ -426,8 +427,8 @@ def end_to_end(wl, rounds=4, arrivals=7):
             n = 1
             for d in shape:
                 n *= d
-            if dtype == torch.float32:
-                out[name] = flat[off:off + n].view(shape).clone()
+            if dtype in floats:
+                out[name] = flat[off:off + n].view(shape).to(dtype, copy=True)
                 off += n
             else:
                 out[name] = torch.full(shape, 3, dtype=dtype)
@@ -906,6 +907,10 @@ def main():
                     e2e = end_to_end(W.WORKLOADS[NORTH_STAR_WORKLOAD], rounds=3, arrivals=3)
                     e2e["workload"] = NORTH_STAR_WORKLOAD
                     out["end_to_end_north_star"] = e2e
+                    # ... and on the same model held in bfloat16 (half the bytes on PCIe and in HBM)
+                    e2e = end_to_end(W.WORKLOADS[NORTH_STAR_WORKLOAD + "_bf16"], rounds=3, arrivals=3)
+                    e2e["workload"] = NORTH_STAR_WORKLOAD + "_bf16"
+                    out["end_to_end_north_star_bf16"] = e2e
         if not a.no_cpu_baseline and bench_class(wl) not in (AdmmBench, MixBench):
             naive, fused = cpu_baseline(wl, a.cpu_seconds)
             out["cpu_baseline"] = naive

@@ -410,6 +410,10 @@ int fa_half_server_opt_step(void* step, void* m, void* v, size_t n, int opt, dou
                             double beta2, double tau, int half, fa_stream_t stream);
 int fa_half_apply_step(void* g, const void* step, size_t n, int half, fa_stream_t stream);
 int fa_half_mean(const void* const* x, int K, void* g, size_t n, int half, fa_stream_t stream);
+/* FedCompass / FedQueue mixes (fedcompass_aggregator.py:152-338, fedqueue_aggregator.py:75-131):
+ * fa_weighted_mix's modes, each x*w, each running sum and the final combine rounded. */
+int fa_half_weighted_mix(const void* const* x, const double* w, int K, void* g, double coeff,
+                         int mode, void* acc_ws, size_t n, int half, fa_stream_t stream);
 /* sub_form != 0 is the reference's optimize_memory branch (fedasync_aggregator.py:243-258), where
  * alpha_t is the `alpha=` of add_ / sub_ and is therefore rounded to the 16-bit type -- for the
  * model-based step too; sub_form == 0 (:260-264) multiplies by the fp32 alpha_t. */

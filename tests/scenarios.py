@@ -499,6 +499,18 @@ def half_scenarios() -> List[Dict]:
                         "kind": "async", "cls": "FedBuffAggregator",
                         "spec": f"toy_{kind}" if with_model else f"ragged_{kind}", "model": with_model,
                         "cfg": cfg, "script": ASYNC_SCRIPT[:6], "sample_sizes": {}})
+        for gb, with_model in ((False, False), (True, True), (False, True)):
+            out.append({"id": f"FedCompass-{kind}-{'grad' if gb else 'model'}-{'model' if with_model else 'nomodel'}",
+                        "kind": "compass", "cls": "FedCompassAggregator",
+                        "spec": f"toy_{kind}" if with_model else f"ragged_{kind}", "model": with_model,
+                        "cfg": dict(STALENESS["polynomial"], alpha=0.9, num_clients=3, gradient_based=gb),
+                        "sample_sizes": {}})
+            out.append({"id": f"FedQueue-{kind}-{'grad' if gb else 'model'}-{'model' if with_model else 'nomodel'}",
+                        "kind": "queue", "cls": "FedQueueAggregator",
+                        "spec": f"toy_{kind}" if with_model else f"ragged_{kind}", "model": with_model,
+                        "cfg": {"staleness_fn": "harmonic", "staleness_fn_kwargs": {"beta": 0.5},
+                                "gradient_based": gb},
+                        "sample_sizes": {0: 12, 1: 30, 2: 7} if gb else {}})
         out.append({"id": f"FedAvg-{kind}-chunked", "kind": "chunked", "cls": "FedAvgAggregator",
                     "spec": f"toy_{kind}", "model": False,
                     "cfg": dict(HP["FedAvgAggregator"], client_weights_mode="equal"),
