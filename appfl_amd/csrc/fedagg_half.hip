@@ -34,7 +34,11 @@ constexpr int kWide = 8;    // elements of a 128-bit load
 // clients, FedAdam, bfloat16, kernel time: 1 x 8 0.623 ms, 2 x 8 / 2 x 4 0.637, 4 x 4 0.631,
 // 1 x 16 0.639 (2 x 16 and 4 x 8 spill); streaming loads of m / v 1.5 % slower; write-through
 // result stores 10 % slower; XCD runs of 32 or 128 tiles 0.7 % faster; with every rounding
-// compiled out 0.611 ms -- the roundings are not what bounds it.
+// compiled out 0.611 ms -- the roundings are not what bounds it.  With the loads in flight kept
+// packed (so that deeper batches fit in registers): 1 x 8 / 1 x 16 / 1 x 32 0.621, 2 x 4 0.622,
+// 2 x 8 0.625, 4 x 8 0.630, 2 x 16 0.634, 4 x 16 0.719: the shape is not what bounds it either;
+// this is where the fp32 tile-per-block kernel sits for the same round (0.70-0.72 of peak), whose
+// persistent, phase-writing successor has no 16-bit counterpart.
 #ifndef FA_HALF_VPT
 #define FA_HALF_VPT 1
 #endif
@@ -130,6 +134,40 @@ __device__ __forceinline__ unsigned narrow2(float lo, float hi) {
         const unsigned b = __builtin_bit_cast(unsigned short, static_cast<_Float16>(hi));
         return a | (b << 16);
     }
+}
+
+// What a load of one element of width VEC leaves in registers before it is widened: the four
+// dwords of a 128-bit access, or the one 16-bit value.  Loads that wait in flight stay in this
+// form (half the registers of the widened one).
+template <int VEC> struct Raw { u4 v; };
+template <> struct Raw<1> { unsigned short v; };
+
+template <int VEC, bool NT>
+__device__ __forceinline__ Raw<VEC> load_raw(const void* p, size_t i) {
+    Raw<VEC> r;
+    if constexpr (VEC == kWide) {
+        const u4* q = static_cast<const u4*>(p) + i;
+        r.v = NT ? __builtin_nontemporal_load(q) : *q;
+    } else {
+        const unsigned short* q = static_cast<const unsigned short*>(p) + i;
+        r.v = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+    return r;
+}
+
+template <int HALF, int VEC>
+__device__ __forceinline__ PackH<VEC> widen(const Raw<VEC>& t) {
+    PackH<VEC> r;
+    if constexpr (VEC == kWide) {
+        widen2<HALF>(t.v.x, r.e[0], r.e[1]);
+        widen2<HALF>(t.v.y, r.e[2], r.e[3]);
+        widen2<HALF>(t.v.z, r.e[4], r.e[5]);
+        widen2<HALF>(t.v.w, r.e[6], r.e[7]);
+    } else {
+        float hi;
+        widen2<HALF>(t.v, r.e[0], hi);
+    }
+    return r;
 }
 
 // element i of width VEC (8: one 128-bit access, 1: one 16-bit access) of a 16-bit buffer
@@ -279,22 +317,24 @@ __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs
         }
         int k = 0;
         for (; k + U <= a.K; k += U) {
-            PackH<VEC> x[U][VPT];
+            Raw<VEC> xr[U][VPT];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int q = 0; q < VPT; ++q) x[u][q] = load_h<HALF, VEC, true>(a.x[k + u], at_[q]);
+                for (int q = 0; q < VPT; ++q) xr[u][q] = load_raw<VEC, true>(a.x[k + u], at_[q]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float w = a.w[k + u];
 #pragma unroll
-                for (int q = 0; q < VPT; ++q)
+                for (int q = 0; q < VPT; ++q) {
+                    const PackH<VEC> x = widen<HALF, VEC>(xr[u][q]);
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        float d = rnd<HALF>(x[u][q].e[e] - g[q].e[e]);
+                        float d = rnd<HALF>(x.e[e] - g[q].e[e]);
                         float wd = rnd<HALF>(d * w);
                         s[q].e[e] = rnd<HALF>(s[q].e[e] + wd);
                     }
+                }
             }
         }
         for (; k < a.K; ++k) {
