@@ -422,17 +422,26 @@ __global__ __launch_bounds__(kThreads) void mean_half_kernel(const MeanHArgs a) 
     }
 }
 
-// MODE 0: model-based a*(x - g); 1: gradient-based "0 - a*x" (zeros.sub_(x, alpha=a));
-// 2: gradient-based "a * (-x)"  (fedasync_aggregator.py:243-264).
+// The step of one arrival (fedasync_aggregator.py:243-264).  MODE 0: model-based a * (x - g);
+// 2: gradient-based a * (-x); and the two forms of the optimize_memory branch, which are ONE
+// tensor operation each -- zeros.add_(d, alpha=a) and zeros.sub_(x, alpha=a) evaluate 0 + a*d and
+// 0 - a*x in fp32 and round once -- MODE 3: model-based, 1: gradient-based.  They differ from
+// the plain products in the sign of a zero: a product that underflows the 16-bit type keeps its
+// sign through the one rounding, and 0 + (-0) is +0.  (PyTorch itself is of two minds here: the
+// vectorised body of its CPU kernel does exactly this, the scalar tail that handles a tensor's
+// last few elements rounds the product first and so returns +0 for every underflow.  The body's
+// form is the one followed; the difference is the sign of a zero STEP and reaches g only where
+// g is -0 itself.)
 template <int MODE, int HALF>
 __device__ __forceinline__ float async_step_h(float x, float g, float alpha) {
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 3) {
         float d = rnd<HALF>(x - g);
-        return rnd<HALF>(alpha * d);
+        float p = alpha * d;
+        return rnd<HALF>(MODE == 3 ? 0.0f + p : p);
     }
     if (MODE == 1) {
-        float ax = rnd<HALF>(alpha * x);
-        return 0.0f - ax;
+        float p = alpha * x;
+        return rnd<HALF>(0.0f - p);
     }
     float nx = -x;
     return rnd<HALF>(alpha * nx);
@@ -674,7 +683,9 @@ void launch_arrival(const void* x, float alpha, void* g, void* step, int first, 
 template <int HALF, bool BUFF>
 int arrival_half(const void* x, float alpha, int gradient_based, int sub_form, void* g, void* step, int first,
                  int flush, size_t n, hipStream_t st) {
-    if (!gradient_based)
+    if (!gradient_based && sub_form)
+        launch_arrival<3, HALF, BUFF>(x, alpha, g, step, first, flush, n, st);
+    else if (!gradient_based)
         launch_arrival<0, HALF, BUFF>(x, alpha, g, step, first, flush, n, st);
     else if (sub_form)
         launch_arrival<1, HALF, BUFF>(x, alpha, g, step, first, flush, n, st);

@@ -400,8 +400,9 @@ class OracleFedAsync(OracleBase):
     def _arrival_step(self, x, g, alpha_t, gradient_based, sub_form):
         a = _sc(alpha_t, g)
         if sub_form and isinstance(g, halfarray.HalfArray):
-            # add_ / sub_(..., alpha=alpha_t) (:246-258) cast alpha to the tensor's own type first
-            a = halfarray.round_scalar(a, g.kind)
+            # zeros.add_(x - g, alpha=alpha_t) / zeros.sub_(x, alpha=alpha_t) (:246-258): one tensor
+            # operation each, alpha cast to the tensor's own type first
+            return halfarray.zeros_axpy(a, x if gradient_based else x - g, -1 if gradient_based else +1)
         if not gradient_based:
             return a * (x - g)                 # :253-258 / :263
         if sub_form:

@@ -168,6 +168,16 @@ class HalfArray:
         return np.negative(self)
 
 
+def zeros_axpy(alpha, b: HalfArray, sign: int) -> HalfArray:
+    """zeros_like(b).add_(b, alpha=alpha) (sign +1) / .sub_(b, alpha=alpha) (sign -1): ONE tensor
+    operation -- 0 +/- alpha * b in fp32 (alpha cast to the tensor's type first), rounded once.
+    Differs from rounding the product first in the sign of a zero result."""
+    a = round_scalar(alpha, b.kind)
+    with np.errstate(all="ignore"):
+        p = (a * b.v).astype(F32)
+        return HalfArray(F32(0.0) + p if sign > 0 else F32(0.0) - p, b.kind)
+
+
 def from_torch(t):
     """A torch bfloat16 / float16 tensor as a HalfArray (exact)."""
     import torch

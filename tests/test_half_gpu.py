@@ -238,3 +238,178 @@ def test_large_round_on_16_bit_carriers(kind):
                     lr=cfg["server_learning_rate"], beta1=cfg["server_momentum_param_1"],
                     beta2=cfg["server_momentum_param_2"], tau=cfg["server_adapt_param"])
     assert np.array_equal(_tbits(g), want["w"].bits())
+
+
+# -- seeded random sweeps: the flat entry points against PyTorch's own CPU arithmetic on 16-bit
+# tensors (the engine the reference's aggregators run on), one torch operation per reference operation
+
+LENGTHS = [1, 2, 7, 8, 9, 63, 64, 255, 2047, 2048, 2049, 4099, 65537]
+
+
+def _rand16(rng, n, kind, scale=0.05):
+    return torch.from_numpy((rng.standard_normal(n) * scale).astype(np.float32)).to(KINDS[kind])
+
+
+def _shifted(t, shift):
+    buf = torch.zeros(t.numel() + 16, dtype=t.dtype, device="cuda")
+    buf[shift:shift + t.numel()].copy_(t)
+    return buf[shift:shift + t.numel()]
+
+
+def _same16(a, b, inputs=()):
+    """Bit equality of two 16-bit tensors (all NaNs alike); on failure the first differing
+    elements are printed with the matching elements of `inputs`."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    nan = b.isnan()
+    ok = (nan & a.isnan()) | (~nan & ~a.isnan() & (a.view(torch.int16) == b.view(torch.int16)))
+    if bool(ok.all()):
+        return True
+    bad = (~ok).nonzero().flatten()[:5]
+    print("differing elements", bad.tolist(), "got", a[bad].float().tolist(), "want", b[bad].float().tolist(),
+          "inputs", [t.detach().cpu()[bad].float().tolist() for t in inputs])
+    return False
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("seed", range(6))
+def test_random_arrivals_means_and_mixes(kind, seed):
+    hops = _hops(kind)
+    rng = np.random.default_rng(77 + seed)
+    for it in range(12):
+        n = int(rng.choice(LENGTHS)) + int(rng.integers(0, 3))
+        shift = int(rng.integers(0, 3)) * int(rng.integers(0, 2))      # 0, or 1-2 elements off alignment
+        what = f"{kind} seed {seed} case {it}: n={n} shift={shift}"
+        g = _rand16(rng, n, kind)
+        x = _rand16(rng, n, kind, 0.06)
+        if n > 4:
+            x[1] = g[1]
+            x[2] = 3.0e30 if it % 3 == 0 else -0.0
+        alpha = float(rng.random() * 0.5 + 0.01)
+        # FedAsync (fedasync_aggregator.py:243-264, :156-160)
+        for gb, sub in ((False, True), (False, False), (True, True), (True, False)):
+            if sub:
+                if gb:
+                    step = torch.zeros_like(x).sub_(x, alpha=alpha)
+                else:
+                    step = torch.zeros_like(x).add_(x.clone().sub_(g, alpha=1), alpha=alpha)
+            else:
+                step = alpha * (-x) if gb else alpha * (x - g)
+            want = g.clone().add_(step, alpha=1)
+            gd, sd = _shifted(g, shift), _shifted(torch.zeros_like(g), shift)
+            hops.async_mix(_shifted(x, shift), alpha, gd, gradient_based=gb, sub_form=sub, step_out=sd, n=n)
+            if sub:
+                # add_ / sub_(..., alpha=) is the one operation where PyTorch's own CPU result depends
+                # on WHERE in the tensor an element sits: its vectorised body evaluates 0 +/- alpha*x in
+                # fp32 and rounds once (a product that underflows keeps its sign: -0), its scalar tail
+                # rounds the product first and then adds it to zero (+0).  The kernels follow the
+                # body; the step is compared with the two zeros taken as equal.
+                step = step + torch.zeros_like(step)
+                sd.add_(torch.zeros_like(sd))
+            assert _same16(gd, want, (x, g)) and _same16(sd, step, (x, g)), what + f" async gb={gb} sub={sub} alpha={alpha!r}"
+        # FedBuff (fedbuff_aggregator.py:145-158, :75-88): three arrivals, the last one flushes
+        for gb in (False, True):
+            buf_ref = torch.zeros_like(g)
+            gd, bd = _shifted(g, shift), _shifted(torch.full_like(g, 7.0), shift)
+            g_ref = g.clone()
+            for a_i in range(3):
+                xa = _rand16(rng, n, kind, 0.06)
+                buf_ref += (alpha * (-xa) if gb else alpha * (xa - g_ref))
+                hops.buff_accum(_shifted(xa, shift), alpha, gd, bd, a_i == 0, gradient_based=gb, flush=a_i == 2, n=n)
+            g_ref = g_ref + buf_ref
+            assert _same16(bd, buf_ref) and _same16(gd, g_ref), what + f" buff gb={gb}"
+        # plain mean and FedBuff's raw sums (fedavg_aggregator.py:285-295, fedbuff_aggregator.py:146-152, :84-86)
+        K = int(rng.choice([1, 3, 8, 17, 130]))
+        xs = [_rand16(rng, n, kind, 0.5) for _ in range(K)]
+        s = torch.zeros_like(g)
+        for t in xs:
+            s.add_(t)
+        md = _shifted(torch.zeros_like(g), shift)
+        hops.mean([_shifted(t, shift) for t in xs], md, n=n)
+        assert _same16(md, s.clone().div_(K)), what + f" mean K={K}"
+        rd = _shifted(torch.full_like(g, 3.0), shift)
+        for i, t in enumerate(xs[:3]):
+            hops.buff_accum_raw(_shifted(t, shift), rd, i == 0, n=n)
+        raw = torch.zeros_like(g)
+        for t in xs[:3]:
+            raw += t
+        assert _same16(rd, raw), what + " raw sum"
+        fd = _shifted(torch.zeros_like(g), shift)
+        hops.buff_flush_mean(fd, rd, 3, n=n)
+        assert _same16(fd, torch.div(raw, 3)), what + " flush mean"
+        # FedCompass / FedQueue mixes (fedcompass_aggregator.py:152-338, fedqueue_aggregator.py:75-131)
+        w = (rng.random(K) * 0.2 + 0.01).tolist()
+        coeff = 1.0 - sum(w)
+        acc = torch.zeros_like(g)
+        for t, wk in zip(xs, w):
+            acc = acc + t * wk
+        sub_ref = g.clone()
+        for t, wk in zip(xs, w):
+            sub_ref = sub_ref - t * wk
+        cases = {"replace": acc, "convex": g * coeff + acc, "subtract": sub_ref, "sum_add": g + acc, "sum_set": acc}
+        if K == 1:
+            cases["convex_one"] = g * coeff + xs[0] * w[0]
+        for mode, want in cases.items():
+            gd = _shifted(g, shift)
+            ws = _shifted(torch.zeros_like(g), shift) if K > hops.kchunk() and mode != "subtract" else None
+            hops.weighted_mix([_shifted(t, shift) for t in xs], w, gd, mode, coeff, acc_ws=ws, n=n)
+            assert _same16(gd, want), what + f" mix {mode} K={K}"
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("seed", range(6))
+def test_random_reduce_rounds(kind, seed):
+    """Random lengths around the 8-element vector and tile boundaries, client counts around the
+    batch and launch limits, misaligned buffers, every optimizer, random hyper-parameters and
+    weights: two rounds of fa_half_reduce_opt against the oracle's aggregator, every bit of g, m, v
+    and of the step handed out."""
+    hops = _hops(kind)
+    rng = np.random.default_rng(4321 + seed)
+    classes = list(CLS_OPT)
+    for it in range(8):
+        n = int(rng.choice(LENGTHS)) + int(rng.integers(0, 3))
+        K = int(rng.choice([1, 2, 7, 8, 9, 16, 33, 128, 129]))
+        if n * K > 3_000_000:
+            K = max(1, 3_000_000 // n)
+        cls = classes[int(rng.integers(0, len(classes)))]
+        opt = CLS_OPT[cls]
+        shift = int(rng.integers(0, 3)) * int(rng.integers(0, 2))
+        cfg = {"client_weights_mode": "sample_size",
+               "server_learning_rate": float(rng.choice([0.1, 0.01, 1.0])),
+               "server_momentum_param_1": float(rng.choice([0.9, 0.5, 0.0])),
+               "server_momentum_param_2": float(rng.choice([0.99, 0.9])),
+               "server_adapt_param": float(rng.choice([1e-3, 1e-8, 0.1]))}
+        ora = OA.ORACLES[cls](None, cfg, None)
+        sizes = {c: int(rng.integers(1, 50)) for c in range(K)}
+        for c, sz in sizes.items():
+            ora.set_client_sample_size(c, sz)
+        tot = sum(sizes.values())
+        w = [sizes[c] / tot for c in range(K)]
+        hp = {}
+        if opt != "none":
+            hp["beta1"] = cfg["server_momentum_param_1"]
+        if opt in ("adam", "yogi", "adagrad"):
+            hp.update(lr=cfg["server_learning_rate"], tau=cfg["server_adapt_param"],
+                      beta2=cfg["server_momentum_param_2"])
+        what = f"{kind} seed {seed} case {it}: n={n} K={K} opt={opt} shift={shift}"
+        g = m = v = None
+        for r in range(2):
+            base, xs = _flat_clients(n, K, kind, seed=11 * seed + 3 * it + r)
+            if n > 4:
+                xs[K - 1][2] = np.float32(3.0e30 if r == 0 else -3.0e30)     # inf in float16
+                xs[K - 1] = _carrier(xs[K - 1], kind)
+            want = ora.aggregate({c: {"w": torch.from_numpy(xs[c]).to(KINDS[kind])} for c in range(K)})
+            if g is None:
+                g = _dev16(xs[0], kind, shift)
+                if opt != "none":
+                    v = _dev16(np.zeros(n, np.float32), kind, shift)
+                    if opt != "avgm":
+                        m = _dev16(np.zeros(n, np.float32), kind, shift)
+                        hops.fill(v, cfg["server_adapt_param"] ** 2)
+            step = _dev16(np.zeros(n, np.float32), kind, shift)
+            hops.reduce_opt([_dev16(x, kind, shift) for x in xs], w, g, m, v, opt, step_out=step, n=n, **hp)
+            assert _same16(g, want["w"].to_torch()), what + f" (g, round {r})"
+            assert _same16(step, ora.last_step["w"].to_torch()), what + f" (step, round {r})"
+            if opt not in ("none", "avgm"):
+                assert _same16(m, ora.m_vector["w"].to_torch()), what + f" (m, round {r})"
+            if opt != "none":
+                assert _same16(v, ora.v_vector["w"].to_torch()), what + f" (v, round {r})"
