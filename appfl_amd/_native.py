@@ -48,6 +48,9 @@ SIGNATURES = {
     "fa_reduce_opt_ex": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, C.c_uint, _p]),
     "fa_debug_scribble_meeting_counters": (_i, [_p]),
     "fa_round": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p, _i, _i, _p, _p]),
+    "fa_round_plan_create": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _i, _p]),
+    "fa_round_plan_launch": (_i, [_p, _p]),
+    "fa_round_plan_destroy": (None, [_p]),
     "fa_reduce_apply": (_i, [_p, _p, _i, _p, _sz, _p, _p]),
     "fa_reduce_opt_static": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p]),
     "fa_reduce_opt_slab": (_i, [_p, _sz, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _p]),

@@ -114,7 +114,8 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         self._folded: Optional[dict] = None
         self._folded_round: Optional[dict] = None     # ... as `_stage` found it for the round being aggregated
         self._fold_flat: Optional[torch.Tensor] = None   # the partial step of the clients folded on arrival
-        self._round_plans: Dict[tuple, Any] = {}  # marshalled arguments of recent fused rounds (ops.RoundPlan)
+        self._round_plans: Dict[tuple, Any] = {}  # kept arguments of recent fused rounds (ops.RoundPlan)
+        self._last_round: Optional[tuple] = None  # the plan of the previous fused round and what it was built from
         self._init_lock()
 
     # -- attributes the reference exposes -------------------------------------------------------
@@ -223,6 +224,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 self._layout.view(self._flats, n).copy_(t.detach())
         self._slab = ClientSlab(self._layout, self.device)
         self._round_plans.clear()        # they point into the state vectors just replaced
+        self._last_round = None
         self._bind_ops()
 
     def _adopt_streamed_state(self) -> None:
@@ -236,6 +238,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             self._layout.view(self._flats, n).copy_(t)
         self._slab = ClientSlab(self._layout, self.device)
         self._round_plans.clear()
+        self._last_round = None
         self._bind_ops()
 
     def _download(self, names=None) -> Dict[str, torch.Tensor]:
@@ -486,10 +489,19 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             hyper = self._hyper()
             plan = None
             if ws is None and hasattr(self._ops, "RoundPlan"):
-                # a steady federation repeats the same call: keep its marshalled arguments
-                key = (K, self._slab.slab.data_ptr(), tuple(self._row_indices(K)), tuple(weights),
-                       self._flats["f32"].data_ptr(), id(self._m), id(self._v), tuple(hyper.values()))
-                plan = self._round_plans.get(key)
+                # a steady federation repeats the same call: keep its arguments.  The round before
+                # this one is recognised by identity of its tensors and equality of the rest, which
+                # is cheaper than building the key of the table of kept plans.
+                rows = self._row_indices(K)
+                last = self._last_round
+                if (last is not None and last[1] is self._slab.slab and last[2] is self._flats["f32"]
+                        and last[3] is self._m and last[4] is self._v and last[5] == weights
+                        and last[6] == rows and last[7] == hyper):
+                    plan = last[0]
+                else:
+                    key = (K, self._slab.slab.data_ptr(), tuple(rows), tuple(weights),
+                           self._flats["f32"].data_ptr(), id(self._m), id(self._v), tuple(hyper.values()))
+                    plan = self._round_plans.get(key)
             if plan is None:
                 means = [(lay.seg_byte[cls], out, lay.count[cls])
                          for cls, out in ((MEAN_F32, self._flats["f32"][n_step:]),
@@ -501,6 +513,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                     plan = self._round_plans[key] = self._ops.RoundPlan(
                         self._rows(K, 0), weights, self._flats["f32"], self._m, self._v, self._OPT,
                         n=n_step, means=means, key=key, **hyper)
+            if plan is not None and (self._last_round is None or self._last_round[0] is not plan):
+                self._last_round = (plan, self._slab.slab, self._flats["f32"], self._m, self._v, list(weights),
+                                    list(rows) if not isinstance(rows, range) else rows, dict(hyper))
             if events:
                 events[0].record()
             if plan is not None:

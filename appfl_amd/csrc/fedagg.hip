@@ -2334,6 +2334,44 @@ int fa_round_resume(const float* const* x, const double* w, int K, int k_done, f
                       n_means, 0, nullptr, k_done, stream);
 }
 
+// A round's arguments, kept on the library's side of the boundary between launches.
+struct fa_round_plan {
+    std::vector<const float*> x;
+    std::vector<double> w;
+    std::vector<fa_mean_segment> means;
+    float *g, *m, *v, *step_ws;
+    size_t n;
+    int opt;
+    double lr, beta1, beta2, tau;
+};
+
+int fa_round_plan_create(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+                         size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                         float* step_ws, const fa_mean_segment* means, int n_means,
+                         fa_round_plan** plan) {
+    if (!plan || !x || !w || K <= 0 || n_means < 0 || (n_means > 0 && !means)) return FA_ERR_INVALID;
+    fa_round_plan* p = new (std::nothrow) fa_round_plan;
+    if (!p) return FA_ERR_INVALID;
+    p->x.assign(x, x + K);
+    p->w.assign(w, w + K);
+    p->means.assign(means, means + n_means);
+    p->g = g; p->m = m; p->v = v; p->step_ws = step_ws;
+    p->n = n; p->opt = opt;
+    p->lr = lr; p->beta1 = beta1; p->beta2 = beta2; p->tau = tau;
+    *plan = p;
+    return FA_OK;
+}
+
+int fa_round_plan_launch(const fa_round_plan* p, fa_stream_t stream) {
+    if (!p) return FA_ERR_INVALID;
+    return round_body(p->x.data(), p->w.data(), static_cast<int>(p->x.size()), p->g, p->m, p->v, p->n, p->opt,
+                      p->lr, p->beta1, p->beta2, p->tau, nullptr, p->step_ws,
+                      p->means.empty() ? nullptr : p->means.data(), static_cast<int>(p->means.size()), 0,
+                      nullptr, 0, stream);
+}
+
+void fa_round_plan_destroy(fa_round_plan* p) { delete p; }
+
 int fa_reduce_apply(const float* const* x, const double* w, int K, float* g, size_t n,
                     float* step_ws, fa_stream_t stream) {
     return fa_reduce_opt(x, w, K, g, nullptr, nullptr, n, FA_OPT_NONE, 0, 0, 0, 0, nullptr,

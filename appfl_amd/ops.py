@@ -160,21 +160,23 @@ def round_sync(x: Sequence, w: Sequence[float], g: torch.Tensor,
 
 
 class RoundPlan:
-    """The marshalled arguments of one `round_sync` call (fa_round without `k_ready`), kept for
-    re-use: a server whose federation is steady launches the same round -- same rows of the same
-    slab, same weights, same state vectors -- every time, and for a small model building the
-    ctypes arrays of K pointers and K weights again costs more than the kernel runs (MNIST-CNN
-    size, 2-10 clients: about half of the ~12 us a call takes).  `launch()` only fetches the
-    current stream and calls the library.  The plan holds references to the tensors it points
-    into; the caller drops it when any of them is replaced."""
+    """The arguments of one `round_sync` call (fa_round without `k_ready`), kept for re-use: a
+    server whose federation is steady launches the same round -- same rows of the same slab, same
+    weights, same state vectors -- every time, and for a small model building the ctypes arrays of
+    K pointers and K weights and converting 19 arguments again costs more than the kernel runs
+    (MNIST-CNN size, 2-10 clients).  The arguments live in a library-side plan
+    (fa_round_plan_create); `launch()` only fetches the current stream and hands over two words
+    (fa_round_plan_launch).  The plan holds references to the tensors it points into; the caller
+    drops it when any of them is replaced."""
 
-    __slots__ = ("_fn", "_args", "_keep", "_device", "key")
+    __slots__ = ("_launch", "_destroy", "_handle", "_keep", "_device", "key")
 
     def __init__(self, x: Sequence, w: Sequence[float], g: torch.Tensor,
                  m: Optional[torch.Tensor] = None, v: Optional[torch.Tensor] = None,
                  opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
                  tau: float = 0.0, step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None,
                  means: Sequence = (), key=None):
+        self._handle = None
         n = g.numel() if n is None else n
         if len(x) != len(w):
             raise ValueError("one weight per client buffer")
@@ -186,21 +188,28 @@ class RoundPlan:
             if out.numel() < count:
                 raise ValueError("mean output shorter than its segment")
             segs[i] = N.MeanSegment(int(off), _dev(out), int(count), _MEAN_DT[out.dtype])
-        rows = _check_rows(x, n, torch.float32)
-        weights = N.double_array([float(t) for t in w])
         f32 = torch.float32
-        self._fn = N.load().fa_round
-        self._args = (rows, weights, len(x), _dev(g, f32), _dev(m, f32), _dev(v, f32), n, OPT_CODES[opt],
-                      float(lr), float(beta1), float(beta2), float(tau), None, _dev(step_ws, f32),
-                      segs, len(means), 0, None)
+        lib = N.load()
+        handle = C.c_void_p()
+        N.check(lib.fa_round_plan_create(
+            _check_rows(x, n, f32), N.double_array([float(t) for t in w]), len(x), _dev(g, f32), _dev(m, f32),
+            _dev(v, f32), n, OPT_CODES[opt], float(lr), float(beta1), float(beta2), float(tau),
+            _dev(step_ws, f32), segs, len(means), C.byref(handle)), "fa_round_plan_create")
+        self._handle = handle.value
+        self._launch, self._destroy = lib.fa_round_plan_launch, lib.fa_round_plan_destroy
         self._keep = (x, g, m, v, step_ws, [out for _, out, _ in means])
         self._device = g.device
         self.key = key
 
     def launch(self) -> None:
-        rc = self._fn(*self._args, torch.cuda.current_stream(self._device).cuda_stream)
+        rc = self._launch(self._handle, torch.cuda.current_stream(self._device).cuda_stream)
         if rc:
-            N.check(rc, "fa_round")
+            N.check(rc, "fa_round_plan_launch")
+
+    def __del__(self):
+        if self._handle is not None:
+            self._destroy(self._handle)
+            self._handle = None
 
 
 def reduce_opt_slab(slab: torch.Tensor, stride: int, w: Sequence[float], g: torch.Tensor,

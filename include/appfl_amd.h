@@ -237,6 +237,25 @@ int fa_round_resume(const float* const* x, const double* w, int K, int k_done, f
                     fa_stream_t stream);
 
 /*
+ * A round whose arguments stay on the library's side between launches (no counterpart in the
+ * reference): a steady federation repeats the same fa_round call -- same rows of the same slab,
+ * same weights, same state vectors -- every round, and for a small model (the MNIST CNN of the
+ * reference's examples, tests/resources/model/cnn.py:6-37) handing the 19 arguments across the
+ * FFI boundary again costs a host as much as the launch itself.  fa_round_plan_create copies x, w
+ * and the mean segments (the device buffers they point to stay the caller's and must outlive the
+ * plan); fa_round_plan_launch(plan, stream) is fa_round(...stored arguments..., step_out = NULL,
+ * k_ready = 0, stream): same routing, same kernels, same bits.  A plan may be launched any number
+ * of times, from one thread at a time.
+ */
+typedef struct fa_round_plan fa_round_plan;
+int fa_round_plan_create(const float* const* x, const double* w, int K, float* g, float* m, float* v,
+                         size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                         float* step_ws, const fa_mean_segment* means, int n_means,
+                         fa_round_plan** plan);
+int fa_round_plan_launch(const fa_round_plan* plan, fa_stream_t stream);
+void fa_round_plan_destroy(fa_round_plan* plan);
+
+/*
  * Server-optimizer epilogue alone, for callers that computed the averaged step themselves:
  * step (in: averaged pseudo-gradient, out: optimizer step), m, v updated in place with the
  * formulas of fa_reduce_opt.  Replaces the part of the subclass compute_steps bodies after

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "appfl_amd.h")).read()
-    declared = set(re.findall(r"^(?:int|float|const char\*)\s+(fa_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|float|void|const char\*)\s+(fa_\w+)\s*\(", header, flags=re.M))
     assert len(declared) >= 25
     lib = N.load()
     for name in declared:

@@ -65,8 +65,11 @@ def main():
             tens = [agg._slab.row_view(k, 0, n_step, torch.float32) for k in range(K)]
             lib = N.load()
             tiny = torch.zeros(4, device="cuda")
+            agg._launch_round(K, w, True)
+            plan = next(iter(agg._round_plans.values()))
             res = {
                 "aggregator launch (kept arguments)": per_call(lambda: agg._launch_round(K, w, True)),
+                "the kept plan's launch alone": per_call(plan.launch),
                 "ops.round_sync (marshalled per call)": per_call(
                     lambda: ops.round_sync(ptrs, w, g, agg._m, agg._v, agg._OPT, n=n_step, **hyper)),
                 "ops.reduce_opt (tensor list)": per_call(
