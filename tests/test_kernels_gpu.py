@@ -940,3 +940,33 @@ def test_round_on_the_late_epilogue_kernel(n_step, K, counts):
         _check_round("adam", HP, n_step, K, counts)
     finally:
         ops.tune()
+
+
+def test_round_plan_launches_equal_marshalled_rounds():
+    """fa_round_plan_create / fa_round_plan_launch: the kept arguments give the bits of fa_round
+    called afresh, round after round, and the plan outlives the Python lists it was built from."""
+    from appfl_amd import ops
+    n, K, tail = 70000, 5, 9
+    base = O.synth_fill(n + tail, 3, scale=0.05)
+    rows = torch.stack([torch.from_numpy(O.synth_fill(n + tail, 40 + k, scale=0.02, base=base)) for k in range(K)]).cuda()
+    cnt = torch.arange(K * 4, dtype=torch.int64, device="cuda").reshape(K, 4).contiguous()
+    w = [0.1, 0.3, 0.2, 0.25, 0.15]
+    hp = dict(lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
+
+    def state():
+        g = torch.from_numpy(base.copy()).cuda()
+        return g, torch.zeros(n, device="cuda"), torch.full((n,), 1e-6, device="cuda")
+
+    g1, m1, v1 = state()
+    g2, m2, v2 = state()
+    ptrs = [rows[k].data_ptr() for k in range(K)]
+    means1 = [(4 * n, g1[n:], tail)]
+    means2 = [(4 * n, g2[n:], tail)]
+    plan = ops.RoundPlan(list(ptrs), list(w), g1, m1, v1, "adam", n=n, means=means1, **hp)
+    for _ in range(3):
+        plan.launch()
+        ops.round_sync(ptrs, w, g2, m2, v2, "adam", n=n, means=means2, **hp)
+    torch.cuda.synchronize()
+    for a, b in ((g1, g2), (m1, m2), (v1, v2)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    del plan
