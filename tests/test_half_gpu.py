@@ -26,7 +26,7 @@ def _hops(kind):
     return half_ops.HalfOps(KINDS[kind])
 
 
-def _carrier(a: np.ndarray, kind: str) -> np.ndarray:
+def _rounded(a: np.ndarray, kind: str) -> np.ndarray:
     return H._ROUND[kind](np.asarray(a, np.float32))
 
 
@@ -68,8 +68,8 @@ def test_device_rounding_equals_torchs_cpu_arithmetic(kind):
 
 
 def _flat_clients(n, K, kind, seed=5):
-    base = _carrier(synth.fill(n, seed, scale=0.05), kind)
-    xs = [_carrier(synth.fill(n, 100 + 3 * seed + k, scale=0.02, base=base), kind) for k in range(K)]
+    base = _rounded(synth.fill(n, seed, scale=0.05), kind)
+    xs = [_rounded(synth.fill(n, 100 + 3 * seed + k, scale=0.02, base=base), kind) for k in range(K)]
     xs[0][: min(n, 3)] = base[: min(n, 3)]
     return base, xs
 
@@ -147,7 +147,7 @@ def test_step_then_optimizer_then_apply_equals_the_fused_call(kind):
 
 
 @pytest.mark.parametrize("kind", list(KINDS))
-def test_aggregator_hands_back_the_callers_dtype_and_exposes_narrowed_state(kind):
+def test_aggregator_hands_back_the_callers_dtype_and_exposes_16_bit_state(kind):
     import appfl_amd.aggregator as A
     dt = KINDS[kind]
     spec = S.SPECS[f"toy_{kind}"]
@@ -222,7 +222,7 @@ def test_what_is_refused_says_so():
 
 
 @pytest.mark.parametrize("kind", list(KINDS))
-def test_large_round_on_16_bit_carriers(kind):
+def test_large_round_on_16_bit_buffers(kind):
     """ResNet-18-sized vector, 12 clients, FedAdam: the 128-bit kernel over many blocks against the
     oracle (every 97th element and a checksum of all)."""
     hops = _hops(kind)
@@ -396,7 +396,7 @@ def test_random_reduce_rounds(kind, seed):
             base, xs = _flat_clients(n, K, kind, seed=11 * seed + 3 * it + r)
             if n > 4:
                 xs[K - 1][2] = np.float32(3.0e30 if r == 0 else -3.0e30)     # inf in float16
-                xs[K - 1] = _carrier(xs[K - 1], kind)
+                xs[K - 1] = _rounded(xs[K - 1], kind)
             want = ora.aggregate({c: {"w": torch.from_numpy(xs[c]).to(KINDS[kind])} for c in range(K)})
             if g is None:
                 g = _dev16(xs[0], kind, shift)
