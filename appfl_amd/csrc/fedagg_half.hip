@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/appfl_amd.h"
 
 namespace {
@@ -28,12 +30,13 @@ constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 1 << 20;
 constexpr int kAhead = 8;   // client loads in flight per element / vector
 constexpr int kWide = 8;    // elements of a 128-bit load
+constexpr size_t kSegmentH = size_t(1) << 30;   // elements one reduce launch covers at most
 
 // Launch shape of the 128-bit reduce kernel: vectors per thread and client loads in flight per
 // vector (build-time knobs for A/B runs; the defaults are the measured best).  ResNet-50 x 64
 // clients, FedAdam, bfloat16, kernel time: 1 x 8 0.623 ms, 2 x 8 / 2 x 4 0.637, 4 x 4 0.631,
 // 1 x 16 0.639 (2 x 16 and 4 x 8 spill); streaming loads of m / v 1.5 % slower; write-through
-// result stores 10 % slower; XCD runs of 32 or 128 tiles 0.7 % faster; with every rounding
+// result stores 2.4 % faster (0.620 -> 0.606 ms); XCD runs of 32 or 128 tiles 0.7 % faster; with every rounding
 // compiled out 0.611 ms -- the roundings are not what bounds it.  With the loads in flight kept
 // packed (so that deeper batches fit in registers): 1 x 8 / 1 x 16 / 1 x 32 0.621, 2 x 4 0.622,
 // 2 x 8 0.625, 4 x 8 0.630, 2 x 16 0.634, 4 x 16 0.719: the shape is not what bounds it either;
@@ -52,7 +55,7 @@ constexpr int kWide = 8;    // elements of a 128-bit load
 #define FA_HALF_XCD_RUN 32     // > 0: inside windows of 8 * RUN tiles each XCD takes RUN consecutive tiles
 #endif
 #ifndef FA_HALF_WT
-#define FA_HALF_WT 0           // 1: results leave with write-through stores
+#define FA_HALF_WT 1           // 1: results leave with write-through stores
 #endif
 
 template <int HALF> struct Elem;
@@ -214,9 +217,10 @@ __device__ __forceinline__ void store_result_h(void* p, size_t i, const PackH<VE
         t.y = narrow2<HALF>(r.e[2], r.e[3]);
         t.z = narrow2<HALF>(r.e[4], r.e[5]);
         t.w = narrow2<HALF>(r.e[6], r.e[7]);
-        u4* q = static_cast<u4*>(p) + i;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(q, 0, 16, 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, 0, 0, 17);
+        // the buffer's base is the same for the whole wave (it lives in scalar registers); the
+        // lane's element goes into the 32-bit offset, which covers the 4 GiB a launch may address
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, -1, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, static_cast<unsigned>(i) * 16u, 0, 17);
     } else {
         store_h<HALF, VEC>(p, i, r);
     }
@@ -633,6 +637,19 @@ int reduce_half(const void* const* x, const double* w, int K, void* g, const voi
         wide = wide && aligned16(x[k]);
     }
     if (n == 0) return FA_OK;
+    if (n > kSegmentH) {
+        // the write-through stores address a buffer through a 32-bit byte offset: one launch
+        // covers at most kSegmentH elements (2 GiB) of every buffer
+        std::vector<const void*> xs(static_cast<size_t>(K));
+        for (size_t off = 0; off < n; off += kSegmentH) {
+            for (int k = 0; k < K; ++k) xs[static_cast<size_t>(k)] = at(x[k], off);
+            int rc = reduce_half(xs.data(), w, K, at(g, off), at(g_ro, off), at(m, off), at(v, off),
+                                 n - off < kSegmentH ? n - off : kSegmentH, opt, h, at(step_out, off),
+                                 at(step_ws, off), apply, half, st);
+            if (rc != FA_OK) return rc;
+        }
+        return FA_OK;
+    }
     const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
     void* carry = step_out ? step_out : step_ws;
     // 128-bit body over the leading whole vectors when every buffer allows it, the 16-bit-access

@@ -413,3 +413,21 @@ def test_random_reduce_rounds(kind, seed):
                 assert _same16(m, ora.m_vector["w"].to_torch()), what + f" (m, round {r})"
             if opt != "none":
                 assert _same16(v, ora.v_vector["w"].to_torch()), what + f" (v, round {r})"
+
+
+def test_a_vector_longer_than_one_launch_segment():
+    """2^30 + 4099 bfloat16 elements: the reduce call is cut into launches of at most 2^30 elements
+    (write-through stores address their buffer through a 32-bit byte offset).  One client of weight
+    1, plain FedAvg: g + (x - g), each operation rounded -- checked against the same two operations
+    by torch on the device, over the cut and at both ends."""
+    hops = _hops("bf16")
+    n = (1 << 30) + 4099
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    g = torch.empty(n, dtype=torch.bfloat16, device="cuda").normal_(0, 0.05, generator=gen)
+    x = torch.empty(n, dtype=torch.bfloat16, device="cuda").normal_(0, 0.05, generator=gen)
+    spots = [slice(0, 70000), slice((1 << 30) - 70000, (1 << 30) + 4099)]
+    want = [g[s] + (x[s] - g[s]) for s in spots]
+    hops.reduce_opt([x], [1.0], g, n=n)
+    torch.cuda.synchronize()
+    for s, w_ in zip(spots, want):
+        assert torch.equal(g[s].view(torch.int16), w_.view(torch.int16))
