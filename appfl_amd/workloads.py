@@ -130,6 +130,11 @@ WORKLOADS: Dict[str, Dict] = {
     # a bfloat16 model: rows and state stay 2 bytes per element, every operation is rounded to bfloat16
     "resnet50_fedadam_k64_bf16": {"table": lambda: as_dtype(resnet(50), torch.bfloat16),
                                   "cls": "FedAdamAggregator", "K": 64},
+    "vitb16_fedasync_bf16": {"table": lambda: as_dtype(vit_b_16(), torch.bfloat16), "cls": "FedAsyncAggregator", "K": 1},
+    "vitb16_fedbuff_flush_bf16": {"table": lambda: as_dtype(vit_b_16(), torch.bfloat16), "cls": "FedBuffAggregator",
+                                  "K": 16, "kind": "flush"},
+    "vitb16_fedcompass_group_k8_bf16": {"table": lambda: as_dtype(vit_b_16(), torch.bfloat16),
+                                        "cls": "FedCompassAggregator", "K": 8, "mode": "convex"},
     "resnet50_fedavg_k64": {"table": lambda: resnet(50), "cls": "FedAvgAggregator", "K": 64},
     "resnet50_fedavgm_k64": {"table": lambda: resnet(50), "cls": "FedAvgMAggregator", "K": 64},
     "vitb16_fedasync": {"table": vit_b_16, "cls": "FedAsyncAggregator", "K": 1},

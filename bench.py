@@ -47,7 +47,7 @@ SHARDED_WORKLOAD = "flat1300m_fedavg_k32"
 NORTH_STAR_WORKLOAD = "resnet50_fedadam_k64"
 SHARDED_EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64"]
 EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "resnet50_fedavgm_k64",
-                   "resnet50_fedadam_k64_bf16",
+                   "resnet50_fedadam_k64_bf16", "vitb16_fedasync_bf16", "vitb16_fedcompass_group_k8_bf16",
                    "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
                    "vitb16_fedbuff_first", "vitb16_fedbuff_middle", "vitb16_fedbuff_flush",
                    "vitb16_fedcompass_group_k8", "vitb16_fedqueue_replace_k16"]
@@ -182,23 +182,35 @@ class AsyncBench:
         if self.buff:
             self.agg._step_flats = lay.alloc_state(self.agg.device)
         self.n_step = lay.count[STEP]
+        half = lay.half_dtype
+        item = 2 if half is not None else 4
         g = self.agg._flats["f32"]
-        ops.synth_fill(g, 7 + 1000003 * rank, scale=0.05, n=lay.n_f32)
         self.agg._slab.slab.zero_()
-        ops.synth_fill(self.agg._slab.row_view(0, 0, lay.n_f32, torch.float32), 1000 + 1000003 * rank,
-                       scale=0.01, base=g, n=lay.n_f32)
+        g32 = g if half is None else torch.empty(lay.n_f32, dtype=torch.float32, device=g.device)
+        ops.synth_fill(g32, 7 + 1000003 * rank, scale=0.05, n=lay.n_f32)
+        if half is None:
+            ops.synth_fill(self.agg._slab.row_view(0, 0, lay.n_f32, torch.float32), 1000 + 1000003 * rank,
+                           scale=0.01, base=g, n=lay.n_f32)
+        else:                      # the same values rounded to the 16-bit type
+            g[:lay.n_f32].copy_(g32)
+            g32.copy_(g[:lay.n_f32])
+            x32 = torch.empty_like(g32)
+            ops.synth_fill(x32, 1000 + 1000003 * rank, scale=0.01, base=g32, n=lay.n_f32)
+            self.agg._slab.row_view(0, 0, lay.n_f32, half).copy_(x32)
+            del g32, x32
         self.K = wl["K"]
         self.i = 0
         self.kind = wl.get("kind")          # FedBuff: time only first / middle / flushing arrivals
-        self.kernel = "buff_accum_kernel" if self.buff else "async_mix_kernel"
+        self.kernel = ("buff_accum_kernel" if self.buff else "async_mix_kernel") if half is None else \
+            "arrival_half_kernel<%s,%s>" % ("buff" if self.buff else "async", str(half).split(".")[-1])
         # x, g read + g write; FedBuff: x, g, step read + step write -- the first arrival of a
         # buffer skips the step read (12) and the flushing one adds the g write (20), so 16 on
         # average over a buffer
         per = {"first": 12, "middle": 16, "flush": 20}.get(self.kind, 16) if self.buff else 12
-        self.alg_bytes = per * self.n_step
+        self.alg_bytes = per * item // 4 * self.n_step
         if self.kind:
             self.kernel += "<%s>" % self.kind
-        self.client_bytes = 4 * lay.n_f32
+        self.client_bytes = item * lay.n_f32
         self.result_numel = lay.n_f32
 
     def step(self, events=None):
@@ -229,25 +241,35 @@ class MixBench:
     fedqueue_aggregator.py:75-131).  One call per step."""
 
     def __init__(self, wl, rank):
-        from appfl_amd import ops, workloads as W
-        self.ops = ops
+        from appfl_amd import half_ops, ops, workloads as W
         rows = wl["table"]()
-        n = self.n_step = W.numel([r for r in rows if r[2] == torch.float32], params_only=True)
+        floats = (torch.float32, torch.bfloat16, torch.float16)
+        dtype = next(r[2] for r in rows if r[2] in floats)
+        half = dtype if dtype != torch.float32 else None
+        item = 2 if half is not None else 4
+        self.ops = ops if half is None else half_ops.HalfOps(half)
+        n = self.n_step = W.numel([r for r in rows if r[2] in floats], params_only=True)
         K = self.K = wl["K"]
         self.mode = wl["mode"]
         stride = (n + 63) // 64 * 64
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.g = torch.empty(n, dtype=torch.float32, device=dev)
-        ops.synth_fill(self.g, 7 + 1000003 * rank, scale=0.05)
-        self.slab = torch.empty((K, stride), dtype=torch.float32, device=dev)
+        g32 = torch.empty(n, dtype=torch.float32, device=dev)
+        ops.synth_fill(g32, 7 + 1000003 * rank, scale=0.05)
+        self.g = g32.to(dtype)
+        g32.copy_(self.g)              # a 16-bit model: the same values, rounded
+        self.slab = torch.empty((K, stride), dtype=dtype, device=dev)
+        x32 = torch.empty_like(g32)
         for k in range(K):
-            ops.synth_fill(self.slab[k], 1000 + k, scale=0.01, base=self.g, n=n)
+            ops.synth_fill(x32, 1000 + k, scale=0.01, base=g32, n=n)
+            self.slab[k, :n].copy_(x32)
+        del g32, x32
         self.rows = [self.slab[k] for k in range(K)]
         self.weights = [0.5 / K] * K if self.mode == "convex" else [1.0 / K] * K
-        self.kernel = "mix_kernel<%s>" % self.mode
+        self.kernel = "mix_kernel<%s>" % self.mode if half is None else \
+            "mix_half_kernel<%s,%s>" % (self.mode, str(half).split(".")[-1])
         # K client reads + g written (replace) or read and written (convex)
-        self.alg_bytes = 4 * (K + (2 if self.mode == "convex" else 1)) * n
-        self.client_bytes = 4 * K * n
+        self.alg_bytes = item * (K + (2 if self.mode == "convex" else 1)) * n
+        self.client_bytes = item * K * n
         self.result_numel = n
 
     def step(self, events=None):
