@@ -106,7 +106,8 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
     def dual_states(self) -> Dict[Any, Dict[str, torch.Tensor]]:
         with self._lock:
             if self._CLIENT_DUALS:
-                return {cid: self._row_views(self._dual_slab.row_view(r, 0, self._n, torch.float32))
+                return {cid: self._row_views(self._dual_slab.row_view(2 * r + self._cur[cid], 0, self._n,
+                                                                      torch.float32))
                         for cid, r in self._rows.items() if cid in self._cur}
             if self._dual is None:
                 return {}
@@ -122,7 +123,9 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
         for slab in self._primal:
             slab.reserve(K)
         if self._CLIENT_DUALS:
-            self._dual_slab.reserve(K)
+            # two dual rows per client, like the primal: a message staged on arrival lands in the
+            # row the current round does not read, and is only adopted when `aggregate` takes it
+            self._dual_slab.reserve(2 * K)
         else:
             self._dual = torch.zeros((K, self._layout.row_bytes // 4), dtype=torch.float32,
                                      device=self.device)
@@ -144,7 +147,7 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
             slab.upload(row, message["primal"])
             if self._CLIENT_DUALS:
                 self._dual_slab.begin_round()
-                self._dual_slab.upload(row, message["dual"])
+                self._dual_slab.upload(2 * row + which, message["dual"])
             self._staged[client_id] = message
 
     def aggregate(self, local_models: Dict[Union[str, int], Union[Dict, OrderedDict, None]],
@@ -187,7 +190,7 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
                         if self._dual_slab not in used:
                             self._dual_slab.begin_round()
                             used.add(self._dual_slab)
-                        self._dual_slab.upload(row, m["dual"])
+                        self._dual_slab.upload(2 * row + which, m["dual"])
                 self.penalty[cid] = m["penalty"]
                 fresh.add(cid)
             self._staged = {}
@@ -201,7 +204,7 @@ class _ADMMAggregator(BaseAggregator, DeviceStateMixin):
                 self._cur[cid] = 1 - self._cur[cid] if cid in self._cur else 0
             primal = [self._primal[self._cur[cid]].row_ptr(self._rows[cid]) for cid in local_models]
             if self._CLIENT_DUALS:
-                dual = [self._dual_slab.row_ptr(self._rows[cid]) for cid in local_models]
+                dual = [self._dual_slab.row_ptr(2 * self._rows[cid] + self._cur[cid]) for cid in local_models]
             else:
                 dual = [self._dual.data_ptr() + self._rows[cid] * self._layout.row_bytes
                         for cid in local_models]

@@ -193,3 +193,30 @@ def test_admm_messages_staged_on_arrival_give_the_same_rounds(cls):
         for k in want:
             assert got[k].numpy().tobytes() == want[k].tobytes(), (r, k)
         assert np.isclose(agg.prim_res, ora.prim_res, rtol=1e-9) and np.isclose(agg.dual_res, ora.dual_res, rtol=1e-9)
+
+
+def test_iceadmm_message_staged_but_not_taken_leaves_the_clients_state_alone():
+    """A message uploaded on arrival that the round then does not use (the scheduler hands `None`
+    for that client, or another message object) must not reach the round: the reference keeps the
+    client's previous primal AND dual (iceadmm_aggregator.py:66-70)."""
+    import appfl_amd.aggregator as A
+    model, ref_model = S.LinearModel(), S.LinearModel()
+    agg, ora = A.ICEADMMAggregator(model, {}, None), OA.ORACLES["ICEADMMAggregator"](ref_model, {}, None)
+    named = [n for n, _ in model.named_parameters()]
+
+    def payload(seed):
+        d = S.make_state(S.LINEAR, seed=seed + 3, gradient=True, scale=0.3, huge=False)
+        return {"primal": S.make_state(S.LINEAR, seed=seed, huge=False), "penalty": 30.0 + seed % 5,
+                "dual": {n: d[n] for n in named}}
+
+    for r in range(4):
+        local = {c: payload(60 * r + c) for c in range(3)}
+        if r == 1:
+            agg.stage(1, payload(999))           # staged, then the round stands by the old message
+            local[1] = None
+        if r == 2:
+            agg.stage(2, payload(998))           # staged, then another message object arrives
+        got, want = agg.aggregate(local), ora.aggregate(local)
+        for k in want:
+            assert got[k].numpy().tobytes() == want[k].tobytes(), (r, k)
+        assert np.isclose(agg.prim_res, ora.prim_res, rtol=1e-9) and np.isclose(agg.dual_res, ora.dual_res, rtol=1e-9)
