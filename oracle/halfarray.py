@@ -22,14 +22,15 @@ F32 = np.float32
 
 def round_bf16(a: np.ndarray) -> np.ndarray:
     """fp32 -> nearest bfloat16 (ties to even), returned as fp32."""
-    a = np.ascontiguousarray(a, F32)
+    shape = np.shape(a)
+    a = np.ascontiguousarray(a, F32).reshape(-1)          # (ascontiguousarray makes 0-d arrays 1-d)
     u = a.view(np.uint32)
     r = (u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) & np.uint32(0xFFFF0000)
     out = r.view(F32).copy()
     nan = np.isnan(a)
     if nan.any():
         out[nan] = np.nan
-    return out
+    return out.reshape(shape)
 
 
 def round_f16(a: np.ndarray) -> np.ndarray:
@@ -105,8 +106,9 @@ class HalfArray:
         """The 16-bit patterns (uint16), which is how records hold these tensors."""
         v = np.where(np.isnan(self.v), F32(np.nan), self.v).astype(F32)      # one quiet NaN for all
         if self.kind == "bf16":
-            return (np.ascontiguousarray(v).view(np.uint32) >> np.uint32(16)).astype(np.uint16)
-        return v.astype(np.float16).view(np.uint16)
+            flat = np.ascontiguousarray(v).reshape(-1)
+            return (flat.view(np.uint32) >> np.uint32(16)).astype(np.uint16).reshape(v.shape)
+        return v.astype(np.float16).reshape(-1).view(np.uint16).reshape(v.shape)
 
     def to_torch(self):
         import torch
