@@ -90,6 +90,8 @@ SIGNATURES = {
     "fa_half_round_scalar": (_f, [_d, _i]),
     "fa_half_reduce_opt": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _i, _p]),
     "fa_half_reduce_step": (_i, [_p, _p, _i, _p, _p, _sz, _i, _p]),
+    "fa_half_reduce_step_resume": (_i, [_p, _p, _i, _i, _p, _p, _sz, _i, _p]),
+    "fa_half_reduce_opt_resume": (_i, [_p, _p, _i, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _i, _p]),
     "fa_half_server_opt_step": (_i, [_p, _p, _p, _sz, _i, _d, _d, _d, _d, _i, _p]),
     "fa_half_apply_step": (_i, [_p, _p, _sz, _i, _p]),
     "fa_half_mean": (_i, [_p, _i, _p, _sz, _i, _p]),

@@ -349,7 +349,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             st["w"] = None
             return
         if self._fold_flat is None:
-            self._fold_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+            self._fold_flat = torch.empty(n_step, dtype=lay.float_dtype, device=self.device)
         compute = torch.cuda.current_stream(self.device)
         compute.wait_event(self._slab.row_event[row - 1])
         st["w"].append(w)
@@ -484,7 +484,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             ws = None
             if K > self._ops.kchunk() or k_ready:
                 if self._step_flat is None:
-                    self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+                    self._step_flat = torch.empty(n_step, dtype=lay.float_dtype, device=self.device)
                 ws = self._step_flat
             hyper = self._hyper()
             plan = None
@@ -637,9 +637,10 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         wins = slab.row_windows.get(rows[-1])
         if not wins or slab.ready_prefix(rows[:-1]) < K - 1:
             return None
-        out_f32 = self._dl.lease(torch.float32, lay.n_f32)
+        out_f32 = self._dl.lease(lay.float_dtype, lay.n_f32)
         if out_f32 is None:
             return None
+        fsize = lay.itemsize(STEP)         # bytes per weighted element in a row: 4, or 2 for a 16-bit model
         self._uploads_pending = False
         if getattr(self, "_down_stream", None) is None:
             self._down_stream = torch.cuda.Stream(device=self.device)
@@ -648,7 +649,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         ws = None
         if K > self._ops.kchunk():
             if self._step_flat is None:
-                self._step_flat = torch.empty(n_step, dtype=torch.float32, device=self.device)
+                self._step_flat = torch.empty(n_step, dtype=lay.float_dtype, device=self.device)
             ws = self._step_flat
         g, ptrs, hyper = self._flats["f32"], self._rows(K, 0), self._hyper()
         # the clients folded on arrival: valid when they are this round's first K - 1 clients in
@@ -662,11 +663,11 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             compute.wait_event(st["event"])
         done = 0
         for a, b, landed in wins:
-            upto = n_step if b >= 4 * n_step else (b // 4) & ~1023      # whole KiB-aligned stretches
+            upto = n_step if b >= fsize * n_step else (b // fsize) & ~1023      # whole KiB-aligned stretches
             if upto <= done:
                 continue
             compute.wait_event(landed)
-            self._ops.round_sync([p + 4 * done for p in ptrs], weights, g[done:],
+            self._ops.round_sync([p + fsize * done for p in ptrs], weights, g[done:],
                                  None if self._m is None else self._m[done:],
                                  None if self._v is None else self._v[done:], self._OPT,
                                  step_ws=None if ws is None else ws[done:], n=upto - done,
@@ -679,7 +680,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
             done = upto
         slab.end_round()                   # the plain means read every row whole
         if done < n_step:                  # (a row whose windows stop short of the weighted segment)
-            self._ops.round_sync([p + 4 * done for p in ptrs], weights, g[done:],
+            self._ops.round_sync([p + fsize * done for p in ptrs], weights, g[done:],
                                  None if self._m is None else self._m[done:],
                                  None if self._v is None else self._v[done:], self._OPT,
                                  step_ws=None if ws is None else ws[done:], n=n_step - done,

@@ -616,15 +616,19 @@ void launch_reduce_half(int opt, const ReduceHArgs& a, hipStream_t st) {
     }
 }
 
+// `k_done` > 0: the partial step of clients 0..k_done-1 is in the carry buffer (step_out, else
+// step_ws) already; the loop over the clients is taken up from there (same order, same bits).
 int reduce_half(const void* const* x, const double* w, int K, void* g, const void* g_ro, void* m, void* v,
                 size_t n, int opt, const HyperH& h, void* step_out, void* step_ws, int apply, int half,
-                hipStream_t st) {
+                hipStream_t st, int k_done = 0) {
     if (!x || !w || K <= 0 || !known(half)) return FA_ERR_INVALID;
+    if (k_done < 0 || k_done >= K) return FA_ERR_INVALID;
+    if (k_done > 0 && !step_out && !step_ws) return FA_ERR_WORKSPACE;
     if (apply ? !g : (!g_ro || !step_out)) return FA_ERR_INVALID;
     if (opt < FA_OPT_NONE || opt > FA_OPT_ADAGRAD) return FA_ERR_INVALID;
     if (opt != FA_OPT_NONE && !v) return FA_ERR_INVALID;
     if (opt >= FA_OPT_ADAM && !m) return FA_ERR_INVALID;
-    if (K > FA_KCHUNK && !step_out && !step_ws) return FA_ERR_WORKSPACE;
+    if (K - k_done > FA_KCHUNK && !step_out && !step_ws) return FA_ERR_WORKSPACE;
     const void* ptrs[] = {g, g_ro, m, v, step_out, step_ws};
     bool wide = true;
     for (const void* p : ptrs) {
@@ -645,12 +649,12 @@ int reduce_half(const void* const* x, const double* w, int K, void* g, const voi
             for (int k = 0; k < K; ++k) xs[static_cast<size_t>(k)] = at(x[k], off);
             int rc = reduce_half(xs.data(), w, K, at(g, off), at(g_ro, off), at(m, off), at(v, off),
                                  n - off < kSegmentH ? n - off : kSegmentH, opt, h, at(step_out, off),
-                                 at(step_ws, off), apply, half, st);
+                                 at(step_ws, off), apply, half, st, k_done);
             if (rc != FA_OK) return rc;
         }
         return FA_OK;
     }
-    const int chunks = (K + FA_KCHUNK - 1) / FA_KCHUNK;
+    const int chunks = (K - k_done + FA_KCHUNK - 1) / FA_KCHUNK;
     void* carry = step_out ? step_out : step_ws;
     // 128-bit body over the leading whole vectors when every buffer allows it, the 16-bit-access
     // kernel over the rest
@@ -658,7 +662,7 @@ int reduce_half(const void* const* x, const double* w, int K, void* g, const voi
     for (int ch = 0; ch < chunks; ++ch) {
         ReduceHArgs a;
         memset(&a, 0, sizeof(a));
-        const int k0 = ch * FA_KCHUNK;
+        const int k0 = k_done + ch * FA_KCHUNK;
         a.K = (K - k0 < FA_KCHUNK) ? K - k0 : FA_KCHUNK;
         a.last = (ch == chunks - 1);
         a.apply = apply;
@@ -675,7 +679,7 @@ int reduce_half(const void* const* x, const double* w, int K, void* g, const voi
             a.g_ro = at(g_ro, lo);
             a.m = at(m, lo);
             a.v = at(v, lo);
-            a.step_in = (ch == 0) ? nullptr : at(static_cast<const void*>(carry), lo);
+            a.step_in = (ch == 0 && k_done == 0) ? nullptr : at(static_cast<const void*>(carry), lo);
             a.step_out = at(a.last ? step_out : carry, lo);
             if (part == 0) {
                 a.n = cnt / kWide;
@@ -748,6 +752,19 @@ int fa_half_reduce_step(const void* const* x, const double* w, int K, const void
                         int half, fa_stream_t stream) {
     return reduce_half(x, w, K, nullptr, g, nullptr, nullptr, n, FA_OPT_NONE, make_hyper_h(0, 0, 0, 0, half),
                        step_out, nullptr, 0, half, as_stream(stream));
+}
+
+int fa_half_reduce_opt_resume(const void* const* x, const double* w, int K, int k_done, void* g, void* m,
+                              void* v, size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                              void* step_ws, int half, fa_stream_t stream) {
+    return reduce_half(x, w, K, g, nullptr, m, v, n, opt, make_hyper_h(lr, beta1, beta2, tau, half), nullptr,
+                       step_ws, 1, half, as_stream(stream), k_done);
+}
+
+int fa_half_reduce_step_resume(const void* const* x, const double* w, int K, int k_done, const void* g,
+                               void* step, size_t n, int half, fa_stream_t stream) {
+    return reduce_half(x, w, K, nullptr, g, nullptr, nullptr, n, FA_OPT_NONE, make_hyper_h(0, 0, 0, 0, half),
+                       step, nullptr, 0, half, as_stream(stream), k_done);
 }
 
 int fa_half_server_opt_step(void* step, void* m, void* v, size_t n, int opt, double lr, double beta1,

@@ -6,9 +6,11 @@ the steps are bfloat16 / float16 tensors, half the bytes of an fp32 model everyw
 call on tensors of its 16-bit type to the ``fa_half_*`` entry points, which widen on load, round
 each operation's result to the 16-bit type exactly where PyTorch's CPU kernels round it in the
 reference (the float path of misc/memory_utils.py:112-131 on a 16-bit tensor) and narrow on
-store; calls on integer or float64 tensors pass through to :mod:`appfl_amd.ops`.  It deliberately
-lacks `round_sync` and `RoundPlan`: the aggregators test for those before taking their fused and
-pipelined fp32 paths, so a 16-bit layout runs the plain sequence of launches.
+store; calls on integer or float64 tensors pass through to :mod:`appfl_amd.ops`.  `round_sync`
+is here a sequence of launches (weighted entries, then each plain-mean segment) with the same
+`k_ready` / `k_done` contract as the fp32 one, so the aggregators' stage-on-arrival folding and
+their pipelined last arrival serve 16-bit models too; there is no `RoundPlan` (the aggregators
+test for it before keeping a round's arguments).
 """
 
 from __future__ import annotations
@@ -55,18 +57,59 @@ class HalfOps:
         N.check(rc, "fa_half_reduce_opt")
 
     def reduce_step(self, x, w, g, step_out, n: Optional[int] = None, k_done: int = 0) -> None:
+        """Weighted step alone into `step_out`; `k_done` > 0: `step_out` holds the partial step of
+        the first `k_done` clients already (fa_half_reduce_step_resume)."""
         if g.dtype != self.dtype:
             return ops.reduce_step(x, w, g, step_out, n, k_done)
-        if k_done:
-            raise NotImplementedError("resumed steps are fp32 only")
         dt = self.dtype
         n = g.numel() if n is None else n
         if step_out.numel() < n:
             raise ValueError("step_out shorter than n")
-        rc = N.load().fa_half_reduce_step(
-            _check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x), _dev(g, dt),
+        rc = N.load().fa_half_reduce_step_resume(
+            _check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x), int(k_done), _dev(g, dt),
             _dev(step_out, dt), n, self.half, _stream(g))
-        N.check(rc, "fa_half_reduce_step")
+        N.check(rc, "fa_half_reduce_step_resume")
+
+    def round_sync(self, x: Sequence, w: Sequence[float], g: torch.Tensor, m=None, v=None, opt: str = "none",
+                   lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0, tau: float = 0.0,
+                   step_ws: Optional[torch.Tensor] = None, n: Optional[int] = None, means: Sequence = (),
+                   k_ready: int = 0, rest_event: Optional["torch.cuda.Event"] = None, k_done: int = 0) -> None:
+        """One synchronous round over K client rows, arguments as `ops.round_sync`: the weighted
+        entries ``g[:n]`` (16-bit) and the plain mean of every ``(row_offset_bytes, out, count)``
+        in `means`, as separate launches.  `k_ready` / `rest_event`: the first `k_ready` clients
+        are folded at once, the others after `rest_event`; `k_done`: the first `k_done` clients are
+        in `step_ws` already."""
+        dt = self.dtype
+        n = g.numel() if n is None else n
+        K = len(x)
+        if K != len(w):
+            raise ValueError("one weight per client buffer")
+        if k_ready and k_done:
+            raise ValueError("k_ready and k_done exclude each other")
+        for t in (m, v, step_ws):
+            if t is not None and t.numel() < n:
+                raise ValueError("state / workspace tensor shorter than n")
+        stream = torch.cuda.current_stream(g.device)
+        split = 0 < k_ready < K
+        if n:
+            if split:
+                if step_ws is None:
+                    raise ValueError("folding the rows that have landed needs step_ws")
+                self.reduce_step(x[:k_ready], w[:k_ready], g, step_ws, n=n)
+                k_done = k_ready
+            if split and rest_event is not None:
+                stream.wait_event(rest_event)
+            rc = N.load().fa_half_reduce_opt_resume(
+                _check_rows(x, n, dt), N.double_array([float(t) for t in w]), K, int(k_done), _dev(g, dt),
+                _dev(m, dt), _dev(v, dt), n, OPT_CODES[opt], float(lr), float(beta1), float(beta2), float(tau),
+                _dev(step_ws, dt), self.half, _stream(g))
+            N.check(rc, "fa_half_reduce_opt_resume")
+        elif split and rest_event is not None:
+            stream.wait_event(rest_event)
+        ptrs = [t if isinstance(t, int) else t.data_ptr() for t in x]
+        for off, out, count in means:
+            if count:
+                self.mean([p + int(off) for p in ptrs], out, n=int(count))
 
     def server_opt_step(self, step, m, v, opt: str, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
                         n: Optional[int] = None) -> None:

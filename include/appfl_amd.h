@@ -425,6 +425,15 @@ int fa_half_reduce_opt(const void* const* x, const double* w, int K, void* g, vo
                        void* step_out, void* step_ws, int half, fa_stream_t stream);
 int fa_half_reduce_step(const void* const* x, const double* w, int K, const void* g, void* step_out,
                         size_t n, int half, fa_stream_t stream);
+/* The client loop cut between two clients, as fa_reduce_step_resume / fa_round_resume cut it
+ * (fedavg_aggregator.py:359-368): `step` / `step_ws` holds the partial step of clients
+ * 0..k_done-1 (0 <= k_done < K; 0: nothing folded yet), the call folds the others -- and, for
+ * fa_half_reduce_opt_resume, finishes the round (optimizer, apply).  Same order, same bits. */
+int fa_half_reduce_step_resume(const void* const* x, const double* w, int K, int k_done, const void* g,
+                               void* step, size_t n, int half, fa_stream_t stream);
+int fa_half_reduce_opt_resume(const void* const* x, const double* w, int K, int k_done, void* g, void* m,
+                              void* v, size_t n, int opt, double lr, double beta1, double beta2,
+                              double tau, void* step_ws, int half, fa_stream_t stream);
 int fa_half_server_opt_step(void* step, void* m, void* v, size_t n, int opt, double lr, double beta1,
                             double beta2, double tau, int half, fa_stream_t stream);
 int fa_half_apply_step(void* g, const void* step, size_t n, int half, fa_stream_t stream);

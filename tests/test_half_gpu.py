@@ -431,3 +431,113 @@ def test_a_vector_longer_than_one_launch_segment():
     torch.cuda.synchronize()
     for s, w_ in zip(spots, want):
         assert torch.equal(g[s].view(torch.int16), w_.view(torch.int16))
+
+
+# -- stage-on-arrival for 16-bit models: the folding of early clients, the pipelined last arrival
+# and the start on the rows that have landed take the same routes as for fp32
+
+def _spec16(kind, n):
+    return {"w": ((n,), kind), "steps": ((3,), "i64"), "b": ((7, 3), kind), "c32": ((5,), "i32")}
+
+
+def _same_records(got, want, what):
+    a, b = S._snap(got), S._snap(want)
+    assert list(a) == list(b), what
+    import golden_util
+    for k in b:
+        assert golden_util.same_bits(a[k], b[k]), (what, k)
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("cls", ["FedAvgAggregator", "FedYogiAggregator"])
+def test_16_bit_round_after_the_last_arrival_runs_as_a_pipeline(kind, cls, monkeypatch):
+    import appfl_amd.aggregator as A
+    from appfl_amd.aggregator.fedavg_aggregator import FedAvgAggregator
+    spec = _spec16(kind, 4_600_003)
+    cfg = dict(S.HP[cls], client_weights_mode="sample_size")
+    agg, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    for a in (agg, ora):
+        for c in range(4):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    taken = []
+    plain = FedAvgAggregator._round_pipelined
+
+    def spy(self, K, weights):
+        out = plain(self, K, weights)
+        taken.append(out is not None)
+        return out
+    monkeypatch.setattr(FedAvgAggregator, "_round_pipelined", spy)
+    monkeypatch.setattr(FedAvgAggregator, "STAGE_WINDOW", 2 << 20)      # several windows per 9 MB row
+    for r, K in enumerate([3, 4, 2]):
+        models = {c: S.make_state(spec, seed=60 * r + c) for c in range(K)}
+        for c, m in models.items():
+            agg.stage(c, m)
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        _same_records(got, want, (kind, cls, r))
+    assert taken[1:] == [True, True], taken
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("cls", ["FedAvgMAggregator", "FedAdamAggregator"])
+def test_16_bit_clients_staged_on_arrival_are_folded_while_the_others_are_awaited(kind, cls, monkeypatch):
+    import appfl_amd.aggregator as A
+    from appfl_amd import half_ops
+    from appfl_amd.aggregator.fedavg_aggregator import FedAvgAggregator
+    spec = _spec16(kind, 4_600_003)
+    K = 5
+    cfg = dict(S.HP[cls], client_weights_mode="sample_size", num_clients=K)
+    agg, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    for a in (agg, ora):
+        for c in range(K):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    resumed = []
+    plain = half_ops.HalfOps.round_sync
+
+    def spy(self, *args, **kw):
+        resumed.append(kw.get("k_done", 0))
+        return plain(self, *args, **kw)
+    monkeypatch.setattr(half_ops.HalfOps, "round_sync", spy)
+    monkeypatch.setattr(FedAvgAggregator, "STAGE_WINDOW", 2 << 20)
+
+    def one_round(r, ids):
+        models = {c: S.make_state(spec, seed=70 * r + c) for c in ids}
+        for c, m in models.items():
+            agg.stage(c, m)
+            torch.cuda.synchronize()
+        del resumed[:]
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        _same_records(got, want, (kind, cls, r))
+        return list(resumed)
+
+    for r in range(2):
+        calls = one_round(r, range(K))
+        assert calls and all(k == K - 1 for k in calls), (r, calls)
+    calls = one_round(2, range(K - 1))          # not the configured round: the guess is dropped
+    assert calls and all(k == 0 for k in calls), calls
+
+
+@pytest.mark.parametrize("landed", ["all_but_last", "half", "one"])
+def test_16_bit_round_starts_on_the_rows_that_have_landed(landed, monkeypatch):
+    import appfl_amd.aggregator as A
+    from appfl_amd.staging import ClientSlab
+
+    def ready_prefix(self, rows):
+        K = len(list(rows))
+        return {"all_but_last": K - 1, "half": (K + 1) // 2, "one": 1}[landed]
+
+    monkeypatch.setattr(ClientSlab, "ready_prefix", ready_prefix)
+    spec = S.SPECS["toy_bf16"]
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size")
+    model = S.MODELS["toy_bf16"]
+    agg, ora = A.FedAdamAggregator(model(), cfg, None), OA.OracleFedAdam(model(), cfg, None)
+    for a in (agg, ora):
+        for c in range(6):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    for r, K in enumerate([4, 6, 2]):
+        models = {c: S.make_state(spec, seed=300 + 10 * r + c) for c in range(K)}
+        truth = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        for c in list(models)[: K - 1]:
+            agg.stage(c, models[c])
+        _same_records(agg.aggregate(models), truth, (landed, r))
