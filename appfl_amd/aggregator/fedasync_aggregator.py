@@ -181,25 +181,26 @@ class FedAsyncAggregator(BaseAggregator, DeviceStateMixin):
         path, so the same bits.  Returns None when it does not apply."""
         lay = self._layout
         n_step = lay.count[STEP]
-        if n_step < self.PIPELINE_MIN_ELEMENTS or lay.n_f64 or lay.half_dtype is not None or any(
+        if n_step < self.PIPELINE_MIN_ELEMENTS or lay.n_f64 or any(
                 not isinstance(t, torch.Tensor) or t.is_cuda for t in local_model.values()):
             return None
-        out_f32 = self._dl.lease(torch.float32, lay.n_f32)
+        out_f32 = self._dl.lease(lay.float_dtype, lay.n_f32)
         if out_f32 is None:
             return None
         if getattr(self, "_down_stream", None) is None:
             self._down_stream = torch.cuda.Stream(device=self.device)
         compute = torch.cuda.current_stream(self.device)
         g = self._flats["f32"]
-        row = self._slab.row_view(0, 0, n_step, torch.float32)
+        fsize = lay.itemsize(STEP)          # bytes per weighted element: 4, or 2 for a 16-bit model
+        row = self._slab.row_view(0, 0, n_step, lay.float_dtype)
         gradient_based = cfg_get(self.aggregator_configs, "gradient_based", False)
         done = 0
 
         def on_window(a: int, b: int, landed) -> None:
             nonlocal done
-            upto = min(n_step, b // 4)          # weighted elements whose bytes have been enqueued
+            upto = min(n_step, b // fsize)      # weighted elements whose bytes have been enqueued
             if upto < n_step:
-                upto -= upto % 4                # keep every piece 16-byte aligned
+                upto -= upto % (16 // fsize)    # keep every piece 16-byte aligned
             if upto <= done:
                 return
             compute.wait_event(landed)
@@ -323,10 +324,10 @@ class FedBuffAggregator(FedAsyncAggregator):
         back while the arrival is still being uploaded: the transfers share the full-duplex
         link instead of queueing.  None when no pinned lease is to be had."""
         lay = self._layout
-        if lay.n_f32 < self.PIPELINE_MIN_ELEMENTS or lay.n_f64 or lay.half_dtype is not None:
+        if lay.n_f32 < self.PIPELINE_MIN_ELEMENTS or lay.n_f64:
             return None
         host = {}
-        for key, dtype, n in (("f32", torch.float32, lay.n_f32), ("i64", torch.int64, lay.count[MEAN_I64]),
+        for key, dtype, n in (("f32", lay.float_dtype, lay.n_f32), ("i64", torch.int64, lay.count[MEAN_I64]),
                               ("i32", torch.int32, lay.count[MEAN_I32])):
             if n == 0:
                 host[key] = torch.empty(0, dtype=dtype)

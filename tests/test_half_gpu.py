@@ -541,3 +541,39 @@ def test_16_bit_round_starts_on_the_rows_that_have_landed(landed, monkeypatch):
         for c in list(models)[: K - 1]:
             agg.stage(c, models[c])
         _same_records(agg.aggregate(models), truth, (landed, r))
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("gradient_based", [False, True])
+def test_16_bit_fedasync_pipelined_arrival_and_fedbuff_early_download(kind, gradient_based, monkeypatch):
+    """The windowed upload / mix / download pipeline of large FedAsync arrivals and FedBuff's early
+    download, forced onto a small 16-bit model with tiny windows: the oracle's records."""
+    import appfl_amd.aggregator as A
+    from appfl_amd import staging
+    spec = S.SPECS[f"ragged_{kind}"]
+    cfg = dict(S.STALENESS["polynomial"], alpha=0.9, num_clients=3, gradient_based=gradient_based)
+    piped, ora = A.FedAsyncAggregator(None, cfg, None), OA.OracleFedAsync(None, cfg, None)
+    piped.PIPELINE_MIN_ELEMENTS = 0
+    taken = []
+    plain_pipe = A.FedAsyncAggregator._arrival_pipelined
+
+    def spy(self, local_model, alpha_t):
+        out = plain_pipe(self, local_model, alpha_t)
+        taken.append(out is not None)
+        return out
+    monkeypatch.setattr(A.FedAsyncAggregator, "_arrival_pipelined", spy)
+    monkeypatch.setattr(staging, "UPLOAD_WINDOW", 64 << 10)
+    for i in range(5):
+        st = S.make_state(spec, seed=800 + 13 * i, gradient=gradient_based, scale=0.01 if gradient_based else 0.02)
+        got = piped.aggregate(i % 3, {k: v.clone() for k, v in st.items()})
+        want = ora.aggregate(i % 3, {k: v.clone() for k, v in st.items()})
+        _same_records(got, want, (kind, "async", i))
+    assert all(taken), taken
+    cfgb = dict(cfg, K=3)
+    early, orab = A.FedBuffAggregator(None, cfgb, None), OA.OracleFedBuff(None, cfgb, None)
+    early.PIPELINE_MIN_ELEMENTS = 0
+    for i in range(7):
+        st = S.make_state(spec, seed=900 + 11 * i, gradient=gradient_based, scale=0.01 if gradient_based else 0.02)
+        got = early.aggregate(i % 3, {k: v.clone() for k, v in st.items()})
+        want = orab.aggregate(i % 3, {k: v.clone() for k, v in st.items()})
+        _same_records(got, want, (kind, "buff", i))
