@@ -135,7 +135,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
 
     def _unrounded_ops(self):
         """`_ops` as it was before a 16-bit layout put the 16-bit operations in its place."""
-        if isinstance(self._ops, half_ops.HalfOps):
+        if getattr(self._ops, "half", None) is not None:     # HalfOps (or a test's stand-in for it)
             return self._plain_ops
         self._plain_ops = self._ops
         return self._ops

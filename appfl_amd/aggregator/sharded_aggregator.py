@@ -26,6 +26,11 @@ Two ways the clients' state dicts reach the ranks (`mode`):
 Integer / non-parameter entries (a few KB) are averaged redundantly on every rank, and so are
 float64 entries (rare and small: they stay whole, with moments of their own, on every rank).
 
+bfloat16 / float16 models run in the sliced mode: blocks, rows, moments and the gathered model
+are 16-bit vectors (half the bytes on the links too) and the arithmetic is the 16-bit kernels'
+(appfl_amd.half_ops), bit-identical to the single-GPU aggregators.  The whole mode refuses
+them: its cross-rank sum would round a 16-bit partial step once per rank.
+
 Collectives happen in `aggregate`, `compute_steps` and `gather_moments` only -- every rank must
 call those, in the same order.  `get_parameters` is local: it serves the model every rank holds
 after the last gather (or the initial state), so one rank may answer client requests at any time
@@ -45,14 +50,16 @@ import torch.distributed as dist
 
 from ..layout import (MEAN_F32, MEAN_F64, MEAN_I32, MEAN_I64, STEP, STEP_F64, Layout,
                       WindowedLayout)
-from ..sharded import ShardMap, gather_rows, round_gather_pipelined, round_whole_update
+from ..sharded import (WHOLE_MODE_16BIT, ShardMap, gather_rows, round_gather_pipelined,
+                       round_whole_update)
 from ..staging import ClientSlab
 from .base_aggregator import cfg_require
 from .fedavg_aggregator import FedAvgAggregator, _native
 
 _OPTS = {"FedAvg": "none", "FedAvgM": "avgm", "FedAdam": "adam", "FedYogi": "yogi",
          "FedAdagrad": "adagrad"}
-_DTYPE_NAMES = {torch.float32: "f32", torch.float64: "f64", torch.int64: "i64", torch.int32: "i32"}
+_DTYPE_NAMES = {torch.float32: "f32", torch.float64: "f64", torch.int64: "i64", torch.int32: "i32",
+                torch.bfloat16: "bf16", torch.float16: "f16"}
 _DTYPES = {v: k for k, v in _DTYPE_NAMES.items()}
 
 
@@ -100,7 +107,7 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
 
     def _ensure_moments(self) -> None:
         L = self._map.L
-        z = dict(dtype=torch.float32, device=self.device)
+        z = dict(dtype=self._full_layout.float_dtype, device=self.device)
         if self._OPT != "none" and self._v is None:
             self._v = torch.zeros(L, **z)
             n64 = self._full_layout.count[STEP_F64]
@@ -128,13 +135,12 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         segment, the small entries whole, and the gathered copy of the weighted segment (built
         locally: every rank sees the same initial values)."""
         full = Layout([(n, tuple(t.shape), t.dtype) for n, t in init.items()], self.named_parameters)
-        if full.half_dtype is not None:
-            raise NotImplementedError("bfloat16 / float16 state dicts are not supported by the sharded "
-                                      "(multi-GPU) aggregator; there is no CPU fallback")
-        smap = ShardMap(full.count[STEP], self.world, self.rank, self._pieces)
+        if full.half_dtype is not None and self.mode == "whole":
+            raise NotImplementedError(WHOLE_MODE_16BIT)      # on every rank: the layout is the same
+        smap = ShardMap(full.count[STEP], self.world, self.rank, self._pieces, full.itemsize(STEP))
         lay = WindowedLayout(full, smap.windows(), smap.L)
         flats = lay.alloc_state(self.device)
-        gathered = torch.zeros(smap.P, dtype=torch.float32, device=self.device)
+        gathered = torch.zeros(smap.P, dtype=full.float_dtype, device=self.device)
         with torch.no_grad():
             for e in lay.entries:
                 src = init[e.name].detach().reshape(-1)[e.src_offset:e.src_offset + e.numel]
@@ -148,6 +154,7 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         # rows: this rank's windows of every client (sliced) or whole client updates (whole)
         self._layout = lay if self.mode == "sliced" else full
         self._slab = ClientSlab(self._layout, self.device)
+        self._bind_ops()
 
     def _init_global_state(self, first_model: Dict[str, torch.Tensor]):
         """fedavg_aggregator.py:228-271 on this rank's blocks."""
@@ -227,7 +234,7 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
             if flat is None:
                 out.append({})
                 continue
-            full = torch.zeros(self._map.P, dtype=torch.float32, device=self.device)
+            full = torch.zeros(self._map.P, dtype=flat.dtype, device=self.device)
             gather_rows(self._map, flat, full, self.group)
             out.append(self._name_views(full, flat64))
         self._moments_full = (out[0], out[1])
@@ -297,7 +304,7 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
         ws = None
         if K > self._ops.kchunk() and smap.n_local:
             if self._step_flat is None:
-                self._step_flat = torch.empty(smap.L, dtype=torch.float32, device=self.device)
+                self._step_flat = torch.empty(smap.L, dtype=full.float_dtype, device=self.device)
             ws = self._step_flat
         round_gather_pipelined(self._ops, smap, self._rows(K, 0) if smap.n_local else [], weights,
                                self._flats["f32"], self._m, self._v, self._OPT, self._hyper(),
@@ -334,9 +341,9 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
             K, weights = len(local_models), self._client_weights(local_models)
             self._ensure_moments()
             if self._step_flat is None:
-                self._step_flat = torch.empty(smap.L, dtype=torch.float32, device=self.device)
+                self._step_flat = torch.empty(smap.L, dtype=full.float_dtype, device=self.device)
             if self._step_full is None:
-                self._step_full = torch.zeros(smap.P, dtype=torch.float32, device=self.device)
+                self._step_full = torch.zeros(smap.P, dtype=full.float_dtype, device=self.device)
             if smap.n_local:
                 self._ops.reduce_step(self._rows(K, 0), weights, self._flats["f32"], self._step_flat,
                                       n=smap.n_local)
@@ -425,7 +432,7 @@ class ShardedFedAvgAggregator(FedAvgAggregator):
                 if t.dtype not in _DTYPE_NAMES:
                     raise NotImplementedError(
                         f"{n}: {t.dtype} entries are not supported by the sharded (multi-GPU) aggregator "
-                        "(fp32, fp64, int64 and int32 are); there is no CPU fallback")
+                        "(fp32, bf16, fp16, fp64, int64 and int32 are); there is no CPU fallback")
             spec[0] = [(n, tuple(t.shape), _DTYPE_NAMES[t.dtype]) for n, t in init.items()]
         if self.world > 1:
             src = dist.get_global_rank(self.group, 0) if self.group is not None else 0

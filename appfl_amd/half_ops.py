@@ -209,11 +209,20 @@ class HalfOps:
                     "fa_half_fill")
 
 
+def for_dtype(dtype: torch.dtype, base=ops):
+    """The operations for vectors of the 16-bit type `dtype`.  `base` is :mod:`appfl_amd.ops` in
+    the product; the CPU stand-in with which the tests rehearse the multi-rank logic under gloo
+    brings its own 16-bit counterpart (`base.for_half(dtype)`)."""
+    if base is ops:
+        return HalfOps(dtype)
+    if hasattr(base, "for_half"):
+        return base.for_half(dtype)
+    raise NotImplementedError("bfloat16 / float16 state dicts need the HIP library's own operations")
+
+
 def for_layout(layout, base):
     """The operations an aggregator uses for `layout`: `base` (normally :mod:`appfl_amd.ops`)
-    when its float entries are fp32 / fp64, a :class:`HalfOps` when they are 16-bit."""
+    when its float entries are fp32 / fp64, the 16-bit ones when they are bfloat16 / float16."""
     if layout is None or layout.half_dtype is None:
         return base
-    if base is not ops:
-        raise NotImplementedError("bfloat16 / float16 state dicts need the HIP library's own operations")
-    return HalfOps(layout.half_dtype)
+    return for_dtype(layout.half_dtype, base)

@@ -184,7 +184,7 @@ class WindowedLayout(Layout):
 
     `windows` = (global_lo, global_hi, local_offset) triples: elements [global_lo, global_hi) of
     the full layout's step segment live at [local_offset, ...) of this rank's step storage, which
-    is `storage` elements long (a multiple of 4; what lies beyond the windows is padding).  Rows
+    is `storage` elements long (a multiple of 16 bytes; what lies beyond the windows is padding).  Rows
     and state vectors keep the shape of :class:`Layout` -- ``[step storage | mean fp32 | ints]``
     -- so the staging slab and the kernels work on them unchanged; `entries` holds one PIECE per
     (step entry, window) intersection, so a name may appear more than once, and the plain-mean
@@ -193,12 +193,10 @@ class WindowedLayout(Layout):
     """
 
     def __init__(self, full: Layout, windows: Sequence[Tuple[int, int, int]], storage: int):
-        if storage % 4:
-            raise ValueError("step storage must be a multiple of 4 elements (16 bytes)")
-        if full.half_dtype is not None:
-            raise NotImplementedError("bfloat16 / float16 state dicts are not supported by the sharded "
-                                      "(multi-GPU) aggregator; there is no CPU fallback")
-        self.half_dtype, self.float_dtype = None, torch.float32
+        self.half_dtype, self.float_dtype = full.half_dtype, full.float_dtype
+        fsize = self.itemsize(STEP)
+        if storage * fsize % 16:
+            raise ValueError("step storage must be a multiple of 16 bytes")
         self.full = full
         self.count = dict(full.count)
         self.count[STEP] = storage
@@ -212,13 +210,13 @@ class WindowedLayout(Layout):
         for e in full.entries:
             if e.cls != STEP:
                 self.entries.append(Entry(e.name, e.shape, e.dtype, e.numel, e.cls, e.offset,
-                                          self.seg_byte[e.cls] + e.offset * _ITEMSIZE[e.cls]))
+                                          self.seg_byte[e.cls] + e.offset * self.itemsize(e.cls)))
                 continue
             for lo, hi, loc in windows:
                 a, b = max(e.offset, lo), min(e.offset + e.numel, hi)
                 if a < b:
                     off = loc + a - lo
-                    self.entries.append(Entry(e.name, e.shape, e.dtype, b - a, STEP, off, 4 * off,
+                    self.entries.append(Entry(e.name, e.shape, e.dtype, b - a, STEP, off, fsize * off,
                                               src_offset=a - e.offset, full_numel=e.numel))
         self.by_name = {}
         self.names = list(full.names)

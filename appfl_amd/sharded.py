@@ -24,6 +24,9 @@ process -- comm/mpi/mpi_server_communicator.py:56-90):
   refreshes the full g.  The cross-rank sum reorders the fp32 additions, so results agree with
   the single-GPU order to ~1e-7 relative, not bit for bit.
 
+Vectors are fp32, or bfloat16 / float16 for a 16-bit model (sliced rounds only; `ShardMap` then
+counts 2-byte elements, so blocks keep their 16- / 256-byte boundaries).
+
 `backend` is the module that provides the flat kernels (default: :mod:`appfl_amd.ops`, the HIP
 library).  It exists ONLY so the tests can rehearse the multi-rank logic on CPU with gloo by
 passing a stand-in; the product never passes it and has no CPU compute path.
@@ -36,34 +39,37 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+WHOLE_MODE_16BIT = ("whole-update rounds are not supported for bfloat16 / float16 models: the cross-rank "
+                    "sum of 16-bit partial steps would be rounded once per rank (up to 2**-8 relative "
+                    "per addition for bfloat16) in an order no single-GPU round has; use sliced rounds")
 PIECE_BYTES = 128 << 20     # a block row is gathered on its own once a shard has several of these
 MAX_PIECES = 8
 
 
-def _round_up4(x: int) -> int:
-    return (x + 3) // 4 * 4
-
-
-def default_pieces(n: int, world: int) -> int:
-    """Blocks per rank: one per PIECE_BYTES of shard, 1..MAX_PIECES.  A function of (n, world)
-    only, so every rank derives the same value."""
-    shard_bytes = 4 * ((n + world - 1) // world)
+def default_pieces(n: int, world: int, itemsize: int = 4) -> int:
+    """Blocks per rank: one per PIECE_BYTES of shard, 1..MAX_PIECES.  A function of (n, world,
+    bytes per element) only, so every rank derives the same value."""
+    shard_bytes = itemsize * ((n + world - 1) // world)
     return max(1, min(MAX_PIECES, shard_bytes // PIECE_BYTES))
 
 
 class ShardMap:
-    """Which elements of an n-element vector rank `rank` of `world` owns, and where."""
+    """Which elements of an n-element vector rank `rank` of `world` owns, and where.
+    `itemsize`: bytes per element (4; 2 for the vectors of a bfloat16 / float16 model)."""
 
-    def __init__(self, n: int, world: int, rank: int, pieces: Optional[int] = None):
+    def __init__(self, n: int, world: int, rank: int, pieces: Optional[int] = None, itemsize: int = 4):
         if n < 0 or world < 1 or not 0 <= rank < world:
             raise ValueError("bad shard geometry")
-        self.n, self.world, self.rank = n, world, rank
-        self.pieces = default_pieces(n, world) if pieces is None else max(1, int(pieces))
+        if itemsize not in (2, 4):
+            raise ValueError("elements of 2 or 4 bytes")
+        self.n, self.world, self.rank, self.itemsize = n, world, rank, itemsize
+        self.pieces = default_pieces(n, world, itemsize) if pieces is None else max(1, int(pieces))
         q = (n + world * self.pieces - 1) // (world * self.pieces)
-        # blocks of a real model start on 256-byte boundaries (64 elements): rows whose blocks
-        # straddle the cache lines of a wave's 1-KiB loads read 5-7 % slower; tiny vectors keep
-        # the 16-byte granularity so that every rank still gets elements
-        self.per = (q + 63) // 64 * 64 if q >= 1024 else max(4, _round_up4(q))
+        # blocks of a real model start on 256-byte boundaries (64 fp32 elements): rows whose
+        # blocks straddle the cache lines of a wave's 1-KiB loads read 5-7 % slower; tiny vectors
+        # keep the 16-byte granularity so that every rank still gets elements
+        big, small = 256 // itemsize, 16 // itemsize
+        self.per = (q + big - 1) // big * big if q >= 1024 else max(small, (q + small - 1) // small * small)
         self.L = self.pieces * self.per          # elements of local storage
         self.P = self.world * self.L             # elements of the padded gathered vector
         self.n_local = sum(self.live(p) for p in range(self.pieces))
@@ -100,10 +106,10 @@ class ShardMap:
         return out
 
 
-def _shift(x, elements: int):
+def _shift(x, elements: int, itemsize: int = 4):
     """Client buffer `x` (device tensor, or a raw device address the caller vouches for) advanced
-    by `elements` fp32 elements."""
-    return x + 4 * elements if isinstance(x, int) else x[elements:]
+    by `elements` elements of `itemsize` bytes."""
+    return x + itemsize * elements if isinstance(x, int) else x[elements:]
 
 
 def gather_rows(smap: ShardMap, g: torch.Tensor, out: torch.Tensor, group=None,
@@ -160,7 +166,7 @@ def round_gather_pipelined(ops, smap: ShardMap, x: Sequence, w: Sequence[float],
     for p in range(smap.pieces):
         a, live = p * smap.per, smap.live(p)
         if live > 0:
-            ops.reduce_opt([_shift(c, a) for c in x], list(w), g[a:],
+            ops.reduce_opt([_shift(c, a, g.element_size()) for c in x], list(w), g[a:],
                            None if m is None else m[a:], None if v is None else v[a:], opt,
                            step_ws=None if step_ws is None else step_ws[a:], n=live, **hp, **extra)
         works += gather_rows(smap, g, out, group, rows=[p], async_op=True)
@@ -205,7 +211,7 @@ def round_whole_update(ops, smap: ShardMap, my_clients: Sequence, my_weights: Se
         a, b = smap.row(p)
         b = min(b, n)
         if len(my_clients) and b > a:
-            ops.reduce_step([_shift(c, a) for c in my_clients], list(my_weights), g_full[a:],
+            ops.reduce_step([_shift(c, a, g_full.element_size()) for c in my_clients], list(my_weights), g_full[a:],
                             partial[a:], n=b - a)
         scatters.append(reduce_scatter_row(smap, partial, step, p, group))
     gathers = []
@@ -227,22 +233,31 @@ def round_whole_update(ops, smap: ShardMap, my_clients: Sequence, my_weights: Se
 class ShardedFlatAggregator:
     def __init__(self, n: int, opt: str = "none", lr: float = 0.0, beta1: float = 0.0,
                  beta2: float = 0.0, tau: float = 0.0, device=None, group=None, backend=None,
-                 pieces: Optional[int] = None):
+                 pieces: Optional[int] = None, dtype: torch.dtype = torch.float32):
+        """`dtype`: torch.float32, or torch.bfloat16 / torch.float16 for a 16-bit model (sliced
+        rounds only: g, m, v and the client slices are then 16-bit vectors and every operation
+        is rounded to that type, as on one GPU)."""
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise NotImplementedError(f"{dtype} vectors are not supported (fp32, bf16 and fp16 are)")
         if backend is None:
             from . import ops as backend   # HIP kernels; raises if the library is not built
+        if dtype != torch.float32:
+            from . import half_ops
+            backend = half_ops.for_dtype(dtype, backend)
         self.ops = backend
+        self.dtype = dtype
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n = n
-        self.map = ShardMap(n, self.world, self.rank, pieces)
+        self.map = ShardMap(n, self.world, self.rank, pieces, torch.empty((), dtype=dtype).element_size())
         self.L = self.map.L
         self.opt = opt
         self.hp = dict(lr=lr, beta1=beta1, beta2=beta2, tau=tau)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = torch.device(device)
-        z = dict(dtype=torch.float32, device=self.device)
+        z = dict(dtype=dtype, device=self.device)
         self.g = torch.zeros(self.L, **z)
         self.m = torch.zeros(self.L, **z) if opt in ("adam", "yogi", "adagrad") else None
         self.v = None
@@ -264,7 +279,7 @@ class ShardedFlatAggregator:
             self.g_full[: self.n].copy_(g_full)
 
     def new_gather_buffer(self) -> torch.Tensor:
-        return torch.zeros(self.map.P, dtype=torch.float32, device=self.device)
+        return torch.zeros(self.map.P, dtype=self.dtype, device=self.device)
 
     def all_gather_global(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """RCCL all-gather of the shards: the padded full vector (first n elements are g)."""
@@ -299,6 +314,8 @@ class ShardedFlatAggregator:
         """One round where this rank holds whole updates of SOME clients (`my_clients[k]` has n
         elements; `my_weights` are their global weights; a rank may hold none): see
         `round_whole_update`."""
+        if self.dtype != torch.float32:
+            raise NotImplementedError(WHOLE_MODE_16BIT)
         smap = self.map
         if self.g_full is None:
             self.g_full = self.all_gather_global()

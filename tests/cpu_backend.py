@@ -109,3 +109,102 @@ _MIX_MODES = {"replace": 0, "convex": 1, "subtract": 2, "convex_one": 3, "sum_ad
 def weighted_mix(x, w, g, mode, coeff=0.0, acc_ws=None, n=None):
     n = g.numel() if n is None else n
     OC.weighted_mix(_rows(x, n), w, _np(g, n), _MIX_MODES[mode], coeff)
+
+
+class _HalfBackend:
+    """The same interface for bfloat16 / float16 vectors, in PyTorch's own CPU arithmetic on
+    16-bit tensors (the arithmetic the reference's server runs for such a model): the op
+    sequences of algorithm/aggregator/fedavg_aggregator.py:276-368 and of the optimizer
+    subclasses.  Calls on other tensors go to the functions above."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.half = {torch.bfloat16: 1, torch.float16: 2}[dtype]
+
+    def for_half(self, dtype):
+        return self if dtype == self.dtype else _HalfBackend(dtype)
+
+    kchunk = staticmethod(kchunk)
+
+    def _rows(self, x, n):
+        out = []
+        for t in x:
+            if isinstance(t, int):
+                t = torch.frombuffer((C.c_char * (2 * n)).from_address(t), dtype=self.dtype)
+            out.append(t[:n])
+        return out
+
+    def fill(self, p, value, n=None):
+        if p.dtype != self.dtype:
+            return fill(p, value, n)
+        (p if n is None else p[:n]).fill_(value)
+
+    def _step(self, x, w, g, n):
+        s = torch.zeros_like(g[:n])
+        for xk, wk in zip(self._rows(x, n), w):
+            s += wk * (xk - g[:n])
+        return s
+
+    def _opt(self, s, m, v, opt, lr, beta1, beta2, tau, n):
+        if opt == "none":
+            return s
+        v = v[:n]
+        if opt == "avgm":
+            v.copy_(beta1 * v + s)
+            return v.clone()
+        m = m[:n]
+        m.copy_(beta1 * m + (1 - beta1) * s)
+        s2 = s * s
+        if opt == "adam":
+            v.copy_(beta2 * v + (1 - beta2) * s2)
+        elif opt == "yogi":
+            v.copy_(v - (s2 * torch.sign(v - s2)) * (1 - beta2))
+        else:
+            v.copy_(v + s2)
+        return torch.div(lr * m, torch.sqrt(v) + tau)
+
+    def reduce_opt(self, x, w, g, m=None, v=None, opt="none", lr=0.0, beta1=0.0, beta2=0.0, tau=0.0,
+                   step_out=None, step_ws=None, n=None, persistent=True):
+        if g.dtype != self.dtype:
+            return reduce_opt(x, w, g, m, v, opt, lr, beta1, beta2, tau, step_out, step_ws, n)
+        n = g.numel() if n is None else n
+        s = self._opt(self._step(x, w, g, n), m, v, opt, lr, beta1, beta2, tau, n)
+        if step_out is not None:
+            step_out[:n].copy_(s)
+        g[:n] += s
+
+    def reduce_step(self, x, w, g, step_out, n=None):
+        if g.dtype != self.dtype:
+            return reduce_step(x, w, g, step_out, n)
+        n = g.numel() if n is None else n
+        step_out[:n].copy_(self._step(x, w, g, n))
+
+    def server_opt_step(self, step, m, v, opt, lr=0.0, beta1=0.0, beta2=0.0, tau=0.0, n=None):
+        if step.dtype != self.dtype:
+            return server_opt_step(step, m, v, opt, lr, beta1, beta2, tau, n)
+        n = step.numel() if n is None else n
+        step[:n].copy_(self._opt(step[:n].clone(), m, v, opt, lr, beta1, beta2, tau, n))
+
+    def apply_step(self, g, step, n=None):
+        if g.dtype != self.dtype:
+            return apply_step(g, step, n)
+        n = g.numel() if n is None else n
+        g[:n] += step[:n]
+
+    def mean(self, x, g, n=None):
+        if g.dtype != self.dtype:
+            return mean(x, g, n)
+        n = g.numel() if n is None else n
+        s = torch.zeros_like(g[:n])
+        for xk in self._rows(x, n):
+            s += xk
+        g[:n].copy_(torch.div(s, len(x)))
+
+    def weighted_mix(self, x, w, g, mode, coeff=0.0, acc_ws=None, n=None):
+        if g.dtype != self.dtype:
+            return weighted_mix(x, w, g, mode, coeff, acc_ws, n)
+        raise NotImplementedError("the 16-bit stand-in covers the FedAvg family only")
+
+
+def for_half(dtype):
+    return _HalfBackend(dtype)

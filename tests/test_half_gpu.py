@@ -209,10 +209,10 @@ def test_stage_bytes_and_user_override_on_a_16_bit_model(kind):
 def test_what_is_refused_says_so():
     import appfl_amd.aggregator as A
     st = S.make_state(S.SPECS["toy_bf16"], seed=3)
-    with pytest.raises(NotImplementedError, match="sharded"):
-        from appfl_amd.layout import Layout, WindowedLayout
-        full = Layout([(n, tuple(t.shape), t.dtype) for n, t in st.items()], None)
-        WindowedLayout(full, [(0, 8, 0)], 8)
+    from appfl_amd.layout import Layout, WindowedLayout
+    full = Layout([(n, tuple(t.shape), t.dtype) for n, t in st.items()], None)
+    with pytest.raises(ValueError, match="16 bytes"):      # 2-byte elements: blocks of 8
+        WindowedLayout(full, [(0, 4, 0)], 4)
     mixed = dict(st)
     mixed["fc.bias"] = mixed["fc.bias"].to(torch.float32)
     with pytest.raises(NotImplementedError, match="mixes"):

@@ -495,3 +495,165 @@ def test_sharded_class_keeps_the_reference_visible_behaviour(world, tmp_path):
                           "flat": torch.cat([sd[n].reshape(-1) for n in names]),
                           "shapes": [(n, tuple(sd[n].shape)) for n in names], "num_examples": 5 + c}
         same(got[f"secure{r}"], sec.aggregate(payload), f"secure{r}")
+
+
+# -- bfloat16 / float16 models: sliced rounds on 16-bit blocks ---------------------------------------
+
+HALF_ROUNDS = [2, 5, 3, 4]
+
+
+def _half_clients(spec, r, K):
+    import scenarios as S
+    local = {c: S.make_state(spec, seed=3100 + 10 * r + c) for c in range(K)}
+    if r == 1:
+        del local[2][next(n for n, (shp, _) in spec.items() if len(shp) == 2)]   # lacks a weighted entry
+    return local
+
+
+def _half_worker(rank, world, port, kind, alg, spec_name, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        spec = S.SPECS[f"{spec_name}_{kind}"]
+        model = S.MODELS[f"toy_{kind}"]() if spec_name == "toy" else None
+        cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode="sample_size")
+        agg = ShardedFedAvgAggregator(model, cfg, None, algorithm=alg, device="cpu", backend=cpu_backend,
+                                      pieces=3)
+        for c in range(5):
+            agg.set_client_sample_size(c, 4 + 3 * c)
+        recs = []
+        for r, K in enumerate(HALF_ROUNDS):
+            local = _half_clients(spec, r, K)
+            if r == 2:
+                for c, m in local.items():          # staged on arrival
+                    agg.stage(c, m)
+            if r == 3:
+                agg.compute_steps(local)            # collective; the step as 16-bit tensors
+                assert all(t.dtype == S.HALF_KINDS[kind] for t in agg.step.values())
+                recs.append(S._snap(agg.step))
+                m, v = agg.gather_moments()
+                recs.append(S._snap(m))
+                recs.append(S._snap(v))
+                break
+            out_r = agg.aggregate(local)
+            assert agg._map.itemsize == 2 and agg._gathered.dtype == S.HALF_KINDS[kind]
+            assert all(out_r[n].dtype == (S.HALF_KINDS[kind] if k == kind else out_r[n].dtype)
+                       for n, (_, k) in spec.items())
+            recs.append(S._snap(out_r))
+            again = agg.get_parameters()            # local, no collective
+            assert all(torch.equal(again[k].reshape(-1).view(torch.uint8), out_r[k].reshape(-1).view(torch.uint8)) for k in out_r)
+        if rank == world - 1:
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,alg,spec_name,world", [("bf16", "FedAdam", "toy", 2), ("f16", "FedYogi", "ragged", 3),
+                                                      ("bf16", "FedAvgM", "ragged", 2), ("f16", "FedAvg", "toy", 2)])
+def test_sliced_rounds_of_a_16_bit_model_match_the_single_process_oracle(kind, alg, spec_name, world, tmp_path):
+    """Every rank holds its blocks of the bfloat16 / float16 rows (2-byte elements in the slab, the
+    state, the moments and the gathered model); results, steps and moments bit for bit those of
+    the oracle's 16-bit arithmetic."""
+    import golden_util
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_half_worker, args=(world, _free_port(), kind, alg, spec_name, out), nprocs=world, join=True)
+    got = list(np.load(out, allow_pickle=True))
+    spec = S.SPECS[f"{spec_name}_{kind}"]
+    model = S.MODELS[f"toy_{kind}"]() if spec_name == "toy" else None
+    cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode="sample_size")
+    ora = OA.ORACLES[alg + "Aggregator"](model, cfg, None)
+    for c in range(5):
+        ora.set_client_sample_size(c, 4 + 3 * c)
+    wants = []
+    for r, K in enumerate(HALF_ROUNDS):
+        local = _half_clients(spec, r, K)
+        if r == 3:
+            ora.compute_steps({c: {k: OA.to_np(v) for k, v in m.items()} for c, m in local.items()})
+            wants += [S._snap(ora.step), S._snap(getattr(ora, "m_vector", {})),
+                      S._snap(getattr(ora, "v_vector", {}))]
+            break
+        wants.append(S._snap(ora.aggregate(local)))
+    assert len(got) == len(wants)
+    for i, (rec, want) in enumerate(zip(got, wants)):
+        assert sorted(rec) == sorted(want), i
+        for k in want:
+            assert golden_util.same_bits(rec[k], want[k]), (i, k)
+
+
+def _half_flat_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        from appfl_amd.sharded import ShardedFlatAggregator
+        agg = ShardedFlatAggregator(N, "adam", device="cpu", backend=cpu_backend, pieces=3,
+                                    dtype=torch.bfloat16, **HP)
+        assert agg.map.itemsize == 2 and agg.map.per % 8 == 0 and agg.g.dtype == torch.bfloat16
+        base, _, _ = _inputs(0)
+        agg.load_global(torch.from_numpy(base).bfloat16())
+        for r in range(ROUNDS):
+            _, xs, w = _inputs(r)
+            full = agg.round_sliced_gather([agg.map.take(torch.from_numpy(x).bfloat16()) for x in xs], w)
+            assert full.dtype == torch.bfloat16 and torch.equal(full, agg.all_gather_global())
+        with pytest.raises(NotImplementedError, match="whole-update"):
+            agg.round_whole([], [])
+        if rank == 0:
+            np.save(out, full[:N].view(torch.int16).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_sliced_rounds_on_bfloat16_vectors(tmp_path):
+    import cpu_backend
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_half_flat_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ops16 = cpu_backend.for_half(torch.bfloat16)
+    base, _, _ = _inputs(0)
+    g = torch.from_numpy(base).bfloat16()
+    m, v = torch.zeros_like(g), torch.zeros_like(g)
+    ops16.fill(v, HP["tau"] ** 2)
+    for r in range(ROUNDS):
+        _, xs, w = _inputs(r)
+        ops16.reduce_opt([torch.from_numpy(x).bfloat16() for x in xs], w, g, m, v, "adam", **HP)
+    assert np.array_equal(np.load(out), g.view(torch.int16).numpy())
+
+
+def _half_whole_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        agg = ShardedFedAvgAggregator(None, {}, None, device="cpu", backend=cpu_backend, mode="whole")
+        local = {c: S.make_state(S.SPECS["toy_bf16"], seed=c) for c in range(4) if c % world == rank}
+        with pytest.raises(NotImplementedError, match="whole-update"):     # on every rank, after the
+            agg.aggregate(local)                                           # collective set-up: nobody hangs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_whole_mode_refuses_a_16_bit_model_on_every_rank():
+    mp.spawn(_half_whole_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_shard_map_of_two_byte_elements():
+    from appfl_amd.sharded import ShardMap, default_pieces
+    for n in (0, 1, 7, 9, 1023, 10007, 25557032):
+        for world in (1, 2, 3, 8):
+            maps = [ShardMap(n, world, r, 2, itemsize=2) for r in range(world)]
+            m0 = maps[0]
+            assert m0.per % 8 == 0 and m0.P >= n            # blocks start on 16-byte boundaries
+            if n > 1024 * world * 2:
+                assert m0.per % 128 == 0                    # ... of a real model on 256-byte ones
+            spans = sorted((lo, hi) for m in maps for lo, hi, _ in m.windows())
+            assert sum(hi - lo for lo, hi in spans) == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert default_pieces(1_300_000_000, 8, 2) == 2 and default_pieces(1_300_000_000, 8) == 4
+    with pytest.raises(ValueError):
+        ShardMap(10, 1, 0, itemsize=8)

@@ -123,6 +123,13 @@ def _two_rank_worker(rank, world, port, out):
             local = {c: S.make_state(S.TOY, seed=700 + 10 * r + c) for c in range(K)}
             recs.append({k: v.numpy().copy() for k, v in agg.aggregate(local).items()})
             print(f"[rank {rank}] state-dict round {r} done", flush=True)
+        # a bfloat16 model: 2-byte blocks, the 16-bit kernels
+        agg16 = ShardedFedAvgAggregator(S.MODELS["toy_bf16"](), cfg, None, algorithm="FedAdam", pieces=3)
+        recs16 = []
+        for r, K in enumerate([3, 2]):
+            local = {c: S.make_state(S.SPECS["toy_bf16"], seed=800 + 10 * r + c) for c in range(K)}
+            recs16.append(S._snap(agg16.aggregate(local)))
+            print(f"[rank {rank}] 16-bit state-dict round {r} done", flush=True)
         # flat aggregator, pipelined and whole-update rounds, on a vector with several block rows
         n, K = 300007, 6
         base = synth.fill(n, 7, scale=0.05)
@@ -139,7 +146,7 @@ def _two_rank_worker(rank, world, port, out):
             print(f"[rank {rank}] flat round {r} done", flush=True)
         g = flat.all_gather_global().cpu().numpy()[:n]
         if rank == 1:
-            np.save(out, np.array([recs, g], dtype=object), allow_pickle=True)
+            np.save(out, np.array([recs, g, recs16], dtype=object), allow_pickle=True)
     finally:
         dist.destroy_process_group()
 
@@ -165,7 +172,7 @@ def test_two_ranks_on_one_gpu_hip_kernels_with_gloo_collectives(tmp_path):
             for p in ctx.processes:
                 p.kill()
             pytest.fail("the two-rank run did not finish within 90 s")
-    recs, g = np.load(out, allow_pickle=True)
+    recs, g, recs16 = np.load(out, allow_pickle=True)
     cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="sample_size")
     ora = OA.OracleFedAdam(S.ToyModel(), cfg, None)
     for c in range(5):
@@ -174,6 +181,12 @@ def test_two_ranks_on_one_gpu_hip_kernels_with_gloo_collectives(tmp_path):
         want = ora.aggregate({c: S.make_state(S.TOY, seed=700 + 10 * r + c) for c in range(K)})
         for k in want:
             assert golden_util.same_bits(recs[r][k], want[k]), (r, k)
+    ora16 = OA.OracleFedAdam(S.MODELS["toy_bf16"](), cfg, None)
+    for r, K in enumerate([3, 2]):
+        want = S._snap(ora16.aggregate({c: S.make_state(S.SPECS["toy_bf16"], seed=800 + 10 * r + c)
+                                        for c in range(K)}))
+        for k in want:
+            assert golden_util.same_bits(recs16[r][k], want[k]), ("bf16", r, k)
     n, K = 300007, 6
     base = synth.fill(n, 7, scale=0.05)
     gw, m, v = base.copy(), np.zeros(n, np.float32), np.full(n, np.float32(HP["tau"] ** 2))
@@ -323,3 +336,91 @@ def test_rounds_kept_off_the_persistent_kernels_give_the_same_bits(opt, K, n):
         outs.append((g, m, v))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# -- bfloat16 / float16 models (sliced rounds) ----------------------------------------------------
+
+def _same_records(got, want, what):
+    import scenarios as S
+    a, b = S._snap(got), S._snap(want)
+    assert list(a) == list(b), what
+    for k in b:
+        assert golden_util.same_bits(a[k], b[k]), (what, k)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("alg,spec_name", [("FedYogi", "toy"), ("FedAvgM", "ragged"), ("FedAvg", "ragged")])
+def test_16_bit_state_dict_sharded_single_rank_matches_plain_aggregator_and_oracle(kind, alg, spec_name):
+    import scenarios as S
+    import appfl_amd.aggregator as A
+    from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+    spec = S.SPECS[f"{spec_name}_{kind}"]
+    model = S.MODELS[f"toy_{kind}"] if spec_name == "toy" else (lambda: None)
+    cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode="sample_size")
+    plain = getattr(A, alg + "Aggregator")(model(), cfg, None)
+    shard = ShardedFedAvgAggregator(model(), cfg, None, algorithm=alg, pieces=3)
+    ora = OA.ORACLES[alg + "Aggregator"](model(), cfg, None)
+    for agg in (plain, shard, ora):
+        for c in range(4):
+            agg.set_client_sample_size(c, 5 + 2 * c)
+    for r, K in enumerate([3, 4, 2]):
+        local = {c: S.make_state(spec, seed=950 + 10 * r + c) for c in range(K)}
+        if r == 1:
+            del local[1][next(n for n, (shp, _) in spec.items() if len(shp) == 2)]
+        want = plain.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
+        truth = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
+        if r == 1:
+            for c, m in local.items():
+                shard.stage(c, m)
+        got = shard.aggregate(local)
+        assert shard._map.itemsize == 2 and shard._gathered.dtype == S.HALF_KINDS[kind]
+        assert shard._slab.row_bytes == shard._layout.row_bytes < 2 * shard._full_layout.row_bytes
+        _same_records(got, want, (r, "plain"))
+        _same_records(got, truth, (r, "oracle"))
+    _same_records(shard.get_parameters(), got, "served")
+    _same_records({k: v.cpu() for k, v in shard.global_state.items()}, got, "global_state")
+    # the step and the moments of a further round
+    local = {c: S.make_state(spec, seed=990 + c) for c in range(3)}
+    shard.compute_steps(local)
+    ora.compute_steps({c: {k: OA.to_np(v) for k, v in m.items()} for c, m in local.items()})
+    _same_records({k: v.cpu() for k, v in shard.step.items()}, ora.step, "step")
+    if alg != "FedAvg":
+        m, v = shard.gather_moments()
+        _same_records({k: t.cpu() for k, t in v.items()}, ora.v_vector, "v")
+        if alg != "FedAvgM":
+            _same_records({k: t.cpu() for k, t in m.items()}, ora.m_vector, "m")
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_flat_sharded_rounds_on_16_bit_vectors_equal_the_unsharded_kernel(kind):
+    """Block rows of a 16-bit vector (several per rank, the last one partial), each reduced by
+    its own launch and gathered: the bits of one launch over the whole vector."""
+    import scenarios as S
+    from appfl_amd import half_ops
+    from appfl_amd.sharded import ShardedFlatAggregator
+    dt = S.HALF_KINDS[kind]
+    n, K = 1_000_003, 6
+    base = torch.from_numpy(synth.fill(n, 7, scale=0.05)).to(dt).cuda()
+    agg = ShardedFlatAggregator(n, "yogi", pieces=5, dtype=dt, **HP)
+    agg.load_global(base)
+    ops16 = half_ops.HalfOps(dt)
+    g, m, v = base.clone(), torch.zeros_like(base), torch.zeros_like(base)
+    ops16.fill(v, HP["tau"] ** 2)
+    for r in range(3):
+        xs = [torch.from_numpy(synth.fill(n, 100 * r + k, scale=0.02)).cuda().add_(base.float()).to(dt)
+              for k in range(K)]
+        w = [(k + 1) / 21 for k in range(K)]
+        ops16.reduce_opt(xs, w, g, m, v, "yogi", **HP)
+        full = agg.round_sliced_gather([agg.map.take(x) for x in xs], w)
+        assert full.dtype == dt and torch.equal(full[:n].view(torch.int16), g.view(torch.int16))
+        assert not full[n:].any()
+    with pytest.raises(NotImplementedError, match="whole-update"):
+        agg.round_whole([], [])
+
+
+def test_whole_mode_refuses_a_16_bit_model():
+    import scenarios as S
+    from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+    agg = ShardedFedAvgAggregator(None, {}, None, mode="whole")
+    with pytest.raises(NotImplementedError, match="whole-update"):
+        agg.aggregate({c: S.make_state(S.SPECS["toy_f16"], seed=c) for c in range(2)})
