@@ -424,3 +424,23 @@ def test_whole_mode_refuses_a_16_bit_model():
     agg = ShardedFedAvgAggregator(None, {}, None, mode="whole")
     with pytest.raises(NotImplementedError, match="whole-update"):
         agg.aggregate({c: S.make_state(S.SPECS["toy_f16"], seed=c) for c in range(2)})
+
+
+def test_16_bit_sharded_round_with_more_clients_than_one_launch_takes():
+    """130 clients: the client list runs as two launches per block row that carry the partial
+    step through a 16-bit workspace of the block's length."""
+    import scenarios as S
+    import appfl_amd.aggregator as A
+    from appfl_amd import ops
+    from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+    K = ops.kchunk() + 2
+    spec = S.SPECS["ragged_bf16"]
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="equal")
+    plain = A.FedAdamAggregator(None, cfg, None)
+    shard = ShardedFedAvgAggregator(None, cfg, None, algorithm="FedAdam", pieces=2)
+    for r in range(2):
+        local = {c: S.make_state(spec, seed=4000 + 200 * r + c, huge=False) for c in range(K)}
+        want = plain.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in local.items()})
+        got = shard.aggregate(local)
+        assert shard._step_flat is not None and shard._step_flat.dtype == torch.bfloat16
+        _same_records(got, want, r)
