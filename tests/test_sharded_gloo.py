@@ -657,3 +657,60 @@ def test_shard_map_of_two_byte_elements():
     assert default_pieces(1_300_000_000, 8, 2) == 2 and default_pieces(1_300_000_000, 8) == 4
     with pytest.raises(ValueError):
         ShardMap(10, 1, 0, itemsize=8)
+
+
+def _half_streamed_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        spec = S.SPECS["toy_bf16"]
+        st = ShardedFedAvgAggregator(None, {}, None, device="cpu", backend=cpu_backend, pieces=2)
+        chunks = S.chunk_keys_by_size(spec, 300)
+        recs = []
+        for r in range(2):
+            states = {c: S.make_state(spec, seed=5400 + 10 * r + c) for c in range(3)}
+            if r == 1:      # a whole round between the streamed ones, on the same state
+                recs.append(S._snap(st.aggregate({c: S.make_state(spec, seed=5450 + c) for c in range(2)})))
+            for ci, keys in enumerate(chunks):
+                o = st.aggregate({c: {k: states[c][k].clone() for k in keys} for c in states},
+                                 _chunk_idx={c: ci for c in states},
+                                 _total_chunks={c: len(chunks) for c in states},
+                                 _chunk_keys={c: list(keys) for c in states})
+                recs.append(S._snap(o))
+        recs.append(S._snap(st.get_parameters()))
+        if rank == world - 1:
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_streamed_rounds_of_a_16_bit_model_on_two_ranks(tmp_path):
+    import golden_util
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_half_streamed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = list(np.load(out, allow_pickle=True))
+    spec = S.SPECS["toy_bf16"]
+    ora = OA.OracleFedAvg(None, {}, None)
+    chunks = S.chunk_keys_by_size(spec, 300)
+    assert len(chunks) > 1
+    wants = []
+    for r in range(2):
+        states = {c: S.make_state(spec, seed=5400 + 10 * r + c) for c in range(3)}
+        if r == 1:
+            wants.append(S._snap(ora.aggregate({c: S.make_state(spec, seed=5450 + c) for c in range(2)})))
+        for ci, keys in enumerate(chunks):
+            wants.append(S._snap(ora.aggregate({c: {k: states[c][k].clone() for k in keys} for c in states},
+                                               _chunk_idx={c: ci for c in states},
+                                               _total_chunks={c: len(chunks) for c in states},
+                                               _chunk_keys={c: list(keys) for c in states})))
+    wants.append(S._snap(ora.get_parameters()))
+    assert len(got) == len(wants)
+    for i, (rec, want) in enumerate(zip(got, wants)):
+        assert list(rec) == list(want), i
+        for k in want:
+            assert golden_util.same_bits(rec[k], want[k]), (i, k)
