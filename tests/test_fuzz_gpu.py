@@ -2,6 +2,8 @@
 boundaries, client counts around the unroll / chunk limits, misaligned sub-buffers (the scalar
 path), every optimizer, optional outputs, every reduce kernel.  Bit-exact throughout."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,8 @@ from appfl_amd import ops
 from oracle import c_oracle as O
 
 pytestmark = pytest.mark.gpu
+# a one-off longer sweep: APPFL_AMD_FUZZ_OFFSET=1000 (2000, ...) moves every seeded case to fresh seeds
+SEED_OFFSET = int(os.environ.get("APPFL_AMD_FUZZ_OFFSET", "0"))
 
 OPTS = [("none", O.OPT_NONE), ("avgm", O.OPT_AVGM), ("adam", O.OPT_ADAM), ("yogi", O.OPT_YOGI),
         ("adagrad", O.OPT_ADAGRAD)]
@@ -34,7 +38,7 @@ def _case(rng):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_reduce_rounds(seed):
-    rng = np.random.default_rng(1234 + seed)
+    rng = np.random.default_rng(1234 + seed + SEED_OFFSET)
     try:
         for it in range(10):
             n, K, opt, code, shift, hp, w = _case(rng)
@@ -81,7 +85,7 @@ def test_random_reduce_rounds(seed):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_mixes_means_and_arrivals(seed):
-    rng = np.random.default_rng(99 + seed)
+    rng = np.random.default_rng(99 + seed + SEED_OFFSET)
     modes = [("replace", 0), ("convex", 1), ("subtract", 2), ("sum_add", 4), ("sum_set", 5)]
     for it in range(10):
         n = int(rng.choice(LENGTHS)) + int(rng.integers(0, 3))
@@ -127,7 +131,7 @@ def test_random_state_dict_rounds(seed):
     import appfl_amd.aggregator as A
     import scenarios as S
     from oracle import aggregators as OA
-    rng = np.random.default_rng(777 + seed)
+    rng = np.random.default_rng(777 + seed + SEED_OFFSET)
     cls = ["FedAvgAggregator", "FedAvgMAggregator", "FedAdamAggregator", "FedYogiAggregator",
            "FedAdagradAggregator"][seed % 5]
     spec = {}
