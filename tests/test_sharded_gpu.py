@@ -444,3 +444,47 @@ def test_16_bit_sharded_round_with_more_clients_than_one_launch_takes():
         got = shard.aggregate(local)
         assert shard._step_flat is not None and shard._step_flat.dtype == torch.bfloat16
         _same_records(got, want, r)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_block_maps_give_the_bits_of_the_unsharded_round(seed):
+    """Random lengths, piece counts, client counts, optimizers and element types: the pipelined
+    sliced round over the block rows against ONE launch over the whole vector."""
+    import os
+    from appfl_amd import half_ops, ops
+    from appfl_amd.sharded import ShardedFlatAggregator
+    rng = np.random.default_rng(31 + seed + int(os.environ.get("APPFL_AMD_FUZZ_OFFSET", "0")))
+    for it in range(8):
+        dt = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+        n = int(rng.choice([1, 5, 63, 1024, 4099, 65537, 300007, 1_000_003])) + int(rng.integers(0, 3))
+        pieces = int(rng.choice([1, 2, 3, 5, 8]))
+        K = int(rng.choice([1, 2, 7, 16, 33, 130]))
+        if n * K > 20_000_000:
+            K = max(1, 20_000_000 // n)
+        opt = ["none", "avgm", "adam", "yogi", "adagrad"][int(rng.integers(0, 5))]
+        hp = dict(lr=float(rng.choice([0.1, 1.0])), beta1=float(rng.choice([0.9, 0.5])),
+                  beta2=float(rng.choice([0.99, 0.9])), tau=float(rng.choice([1e-3, 0.1])))
+        what = f"seed {seed} case {it}: {dt} n={n} pieces={pieces} K={K} {opt}"
+        o = ops if dt == torch.float32 else half_ops.HalfOps(dt)
+        base = torch.from_numpy(synth.fill(n, 7 + it, scale=0.05)).cuda().to(dt)
+        agg = ShardedFlatAggregator(n, opt, pieces=pieces, dtype=dt, **hp)
+        agg.load_global(base)
+        g = base.clone()
+        m = torch.zeros_like(g) if opt in ("adam", "yogi", "adagrad") else None
+        v = None
+        if opt != "none":
+            v = torch.zeros_like(g)
+            if opt != "avgm":
+                o.fill(v, hp["tau"] ** 2)
+        w = (rng.random(K) + 0.05)
+        w = (w / w.sum()).tolist()
+        for r in range(2):
+            xs = [(torch.from_numpy(synth.fill(n, 100 * r + k + 1000 * it, scale=0.02)).cuda() + base.float()).to(dt)
+                  for k in range(K)]
+            ws = torch.zeros(n, dtype=dt, device="cuda") if K > ops.kchunk() else None
+            o.reduce_opt(xs, w, g, m, v, opt, step_ws=ws, **hp)
+            ws_l = torch.zeros(agg.L, dtype=dt, device="cuda") if K > ops.kchunk() else None
+            full = agg.round_sliced_gather([agg.map.take(x) for x in xs], w, step_ws=ws_l)
+            bits = torch.int32 if dt == torch.float32 else torch.int16
+            assert torch.equal(full[:n].view(bits), g.view(bits)), what + f" round {r}"
+            assert not full[n:].any(), what
