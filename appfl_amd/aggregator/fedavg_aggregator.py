@@ -390,6 +390,16 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         `_launch_round` then starts on the rows that have landed while the last ones travel."""
         if self._staged_for is not None and self._staged_for is local_models:
             return
+        if self._init_client is not None and self.model is None and local_models:
+            # before the first round, no model: `stage` started the global state from the first
+            # client STAGED; the reference starts it from the round's first client (:260-271).
+            # Under the schedulers the two are one object; if they are not, start over from the
+            # round's (rows staged so far may hold fills from the void state, so they go too)
+            first_id = next(iter(local_models))
+            staged = self._prestaged.get(first_id)
+            if first_id != self._init_client or staged is None or staged[1] is not local_models[first_id]:
+                self._init_global_state(local_models[first_id])
+                self._prestaged, self._next_row, self._folded, self._restaged = {}, 0, None, False
         K = len(local_models)
         taken = self._next_row
         reuse = {cid: row for cid, (row, model) in self._prestaged.items()
@@ -476,7 +486,7 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
                 # (a client staged on arrival leaves about one row's transfer to hide: the
                 # ResNet-18 x 100 round then ends 0.6 ms earlier)
                 k_ready = self._slab.ready_prefix(self._row_of if len(self._row_of) == K else range(K))
-                if K // 2 <= k_ready < K:
+                if max(1, K // 2) <= k_ready < K:      # (no landed row: nothing to start on -- wait)
                     rest = self._slab.last_copy
                 else:
                     k_ready = 0

@@ -1,0 +1,86 @@
+"""Randomised rounds through the stage-on-arrival machinery of the aggregators (clients uploaded
+on arrival in random order and number, folded while the others are awaited, the last arrival
+pipelined with the kernels, clients staged twice, clients lacking an entry, changing client
+counts), every result bit for bit against the oracle.  The paths differ in stream and event
+ordering only, so what this looks for is a result that depends on timing."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util
+import scenarios as S
+from oracle import aggregators as OA
+
+pytestmark = pytest.mark.gpu
+SEED_OFFSET = int(os.environ.get("APPFL_AMD_FUZZ_OFFSET", "0"))
+CLASSES = ["FedAvgAggregator", "FedAvgMAggregator", "FedAdamAggregator", "FedYogiAggregator"]
+
+
+def _spec(kind, n):
+    return {"w": ((n,), kind), "steps": ((3,), "i64"), "b": ((7, 3), kind), "c32": ((5,), "i32"),
+            "v": ((n // 3 + 1,), kind)}
+
+
+def _same(got, want, what):
+    a, b = S._snap(got), S._snap(want)
+    assert list(a) == list(b), what
+    for k in b:
+        assert golden_util.same_bits(a[k], b[k]), (what, k)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_staged_rounds(seed, monkeypatch):
+    import appfl_amd.aggregator as A
+    from appfl_amd.aggregator.fedavg_aggregator import FedAvgAggregator
+    rng = np.random.default_rng(9000 + seed + SEED_OFFSET)
+    kind = ["f32", "bf16", "f16"][int(rng.integers(0, 3))]
+    cls = CLASSES[int(rng.integers(0, len(CLASSES)))]
+    n = int(rng.choice([70_001, 600_003, 4_600_003, 4_600_003, 5_100_001]))
+    monkeypatch.setattr(FedAvgAggregator, "STAGE_WINDOW", int(rng.choice([1, 2, 8])) << 20)
+    spec = _spec(kind, n)
+    cfg = dict(S.HP[cls], client_weights_mode=str(rng.choice(["sample_size", "equal"])))
+    agg, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    for a in (agg, ora):
+        for c in range(8):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    for r in range(5):
+        K = int(rng.integers(1, 8))
+        ids = [int(c) for c in rng.permutation(8)[:K]]
+        models = {c: S.make_state(spec, seed=100_000 * seed + 100 * r + c, huge=False) for c in ids}
+        if K > 1 and r and rng.random() < 0.3:
+            del models[ids[-1]]["v"]                     # a client lacking a weighted entry
+        # what the scheduler was configured with: the round's size (the folding of early clients
+        # relies on it), another size, or nothing
+        hint = [K, K, K + 1, 0][int(rng.integers(0, 4))]
+        agg.aggregator_configs["num_clients"] = hint
+        if rng.random() < 0.6:                           # as a scheduler would: in arrival order
+            order = ids[:int(rng.integers(max(K - 1, 0), K + 1))]
+        else:                                            # some clients, in any order
+            order = [ids[i] for i in rng.permutation(K)[:int(rng.integers(0, K + 1))]]
+        what = f"seed {seed} {cls} {kind} n={n} round {r}: clients {ids}, staged {order}, num_clients {hint}"
+        for c in order:
+            agg.stage(c, models[c])
+        if order and rng.random() < 0.25:
+            agg.stage(order[0], models[order[0]])        # the same client again
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        _same(got, want, what)
+        if rng.random() < 0.5:
+            _same(agg.get_parameters(), want, what + " (served)")
+
+
+@pytest.mark.parametrize("kind", ["f32", "bf16"])
+def test_single_client_rounds_wait_for_their_upload(kind):
+    """One client per round, not staged on arrival: the kernel may only start once that client's
+    row has landed (with no landed row there is nothing to start on early)."""
+    import appfl_amd.aggregator as A
+    spec = _spec(kind, 6_000_001)
+    agg, ora = A.FedAvgAggregator(None, {}, None), OA.OracleFedAvg(None, {}, None)
+    for r in range(4):
+        models = {0: S.make_state(spec, seed=77 + r, huge=False)}
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        _same(got, want, (kind, r))
