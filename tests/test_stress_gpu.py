@@ -84,3 +84,36 @@ def test_single_client_rounds_wait_for_their_upload(kind):
         got = agg.aggregate(models)
         want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
         _same(got, want, (kind, r))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_async_arrivals(seed):
+    """FedAsync / FedBuff: random arrival orders, downloads in between, model sizes on both
+    sides of the pipelined arrival's threshold, every staleness function; each reply against
+    the oracle (the pipelined arrival and FedBuff's early download overlap three streams)."""
+    import appfl_amd.aggregator as A
+    rng = np.random.default_rng(7000 + seed + SEED_OFFSET)
+    kind = ["f32", "bf16", "f16"][int(rng.integers(0, 3))]
+    cls = ["FedAsyncAggregator", "FedBuffAggregator"][int(rng.integers(0, 2))]
+    n = int(rng.choice([70_001, 600_003, 4_600_003, 5_100_001]))
+    spec = _spec(kind, n)
+    stale = dict(list(S.STALENESS.values())[int(rng.integers(0, len(S.STALENESS)))])
+    cfg = dict(stale, alpha=float(rng.choice([0.9, 0.5])), num_clients=4,
+               gradient_based=bool(rng.integers(0, 2)), optimize_memory=bool(rng.integers(0, 2)),
+               client_weights_mode=str(rng.choice(["sample_size", "equal"])))
+    if cls == "FedBuffAggregator":
+        cfg["K"] = int(rng.integers(1, 4))
+    agg, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    for a in (agg, ora):
+        for c in range(4):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    for it in range(10):
+        c = int(rng.integers(0, 4))
+        what = f"seed {seed} {cls} {kind} n={n} cfg={cfg} arrival {it} of client {c}"
+        model = S.make_state(spec, seed=100_000 * seed + 10 * it + c, huge=False, gradient=cfg["gradient_based"])
+        got = agg.aggregate(c, model)
+        want = ora.aggregate(c, {k: v.clone() for k, v in model.items()})
+        _same(got, want, what)
+        if rng.random() < 0.4:
+            d = int(rng.integers(0, 4))
+            _same(agg.get_parameters(client_id=d), ora.get_parameters(client_id=d), what + f" (download by {d})")
