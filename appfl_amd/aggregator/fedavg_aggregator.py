@@ -278,7 +278,9 @@ class FedAvgAggregator(BaseAggregator, DeviceStateMixin):
         is equally valid.  The first staged client of the first round initialises the global
         state exactly as the first client of `aggregate` would (:228-271)."""
         with self._lock:
-            if self._layout is None:
+            if self._layout is None and self._extra_state:
+                self._adopt_streamed_state()        # streamed rounds built the state already
+            elif self._layout is None:
                 self._init_global_state(local_model)
                 self._init_client = client_id
             elif client_id == self._init_client and self.model is None:

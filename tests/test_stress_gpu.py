@@ -117,3 +117,59 @@ def test_random_async_arrivals(seed):
         if rng.random() < 0.4:
             d = int(rng.integers(0, 4))
             _same(agg.get_parameters(client_id=d), ora.get_parameters(client_id=d), what + f" (download by {d})")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_api_sequences(seed):
+    """Whole rounds (some staged on arrival), streamed rounds chunk by chunk, chunked and whole
+    `get_parameters`, in random order on one aggregator, with or without a model: every reply
+    against the oracle."""
+    import appfl_amd.aggregator as A
+    rng = np.random.default_rng(8000 + seed + SEED_OFFSET)
+    kind = ["f32", "bf16"][int(rng.integers(0, 2))]
+    cls = CLASSES[int(rng.integers(0, len(CLASSES)))]
+    with_model = bool(rng.integers(0, 2))
+    spec_name = "toy" if kind == "f32" else f"toy_{kind}"
+    spec = S.SPECS[spec_name]
+    cfg = dict(S.HP[cls], client_weights_mode=str(rng.choice(["sample_size", "equal"])))
+    mk = S.MODELS[spec_name] if with_model else (lambda: None)
+    agg, ora = getattr(A, cls)(mk(), cfg, None), OA.ORACLES[cls](mk(), cfg, None)
+    for a in (agg, ora):
+        for c in range(6):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    chunk_bytes = int(rng.choice([200, 600, 1500]))
+    chunks = S.chunk_keys_by_size(spec, chunk_bytes)
+    for a in (agg, ora):
+        a.set_model_chunk_size(chunk_bytes)
+    for it in range(12):
+        act = int(rng.integers(0, 4))
+        what = f"seed {seed} {cls} {kind} model={with_model} step {it} action {act}"
+        K = int(rng.integers(1, 6))
+        ids = [int(c) for c in rng.permutation(6)[:K]]
+        states = {c: S.make_state(spec, seed=100_000 * seed + 100 * it + c) for c in ids}
+        if act == 0:                                     # a whole round, some clients staged on arrival
+            for c in ids[:int(rng.integers(0, K + 1))]:
+                agg.stage(c, states[c])
+            _same(agg.aggregate(states),
+                  ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in states.items()}), what)
+        elif act == 1:                                   # a streamed round
+            for ci, keys in enumerate(chunks):
+                kw = dict(_chunk_idx={c: ci for c in ids}, _total_chunks={c: len(chunks) for c in ids},
+                          _chunk_keys={c: list(keys) for c in ids})
+                got = agg.aggregate({c: {k: states[c][k].clone() for k in keys} for c in ids}, **kw)
+                want = ora.aggregate({c: {k: states[c][k].clone() for k in keys} for c in ids}, **kw)
+                _same(got, want, what + f" chunk {ci}")
+        elif act == 2:                                   # a chunked download
+            if not with_model and ora.global_state is None:
+                continue
+            cid = int(rng.integers(0, len(chunks)))
+            kw = {"_request_chunked": True} if rng.random() < 0.5 else {"_chunk_id": cid}
+            got, want = agg.get_parameters(**kw), ora.get_parameters(**kw)
+            if isinstance(want, tuple):
+                assert got[1] == want[1], what
+                got, want = got[0], want[0]
+            _same(got, want, what + f" {kw}")
+        else:
+            if not with_model and ora.global_state is None:
+                continue
+            _same(agg.get_parameters(), ora.get_parameters(), what)
