@@ -173,3 +173,40 @@ def test_random_api_sequences(seed):
             if not with_model and ora.global_state is None:
                 continue
             _same(agg.get_parameters(), ora.get_parameters(), what)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_rounds_of_the_sharded_class_on_one_rank(seed):
+    """The sharded state-dict aggregator on one rank (both modes, random piece counts, staged
+    arrivals, changing client sets) against the plain aggregator's oracle: with one rank no
+    collective reorders anything, so every bit must agree."""
+    from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+    rng = np.random.default_rng(6000 + seed + SEED_OFFSET)
+    mode = ["sliced", "whole"][int(rng.integers(0, 2))]
+    kind = "f32" if mode == "whole" else ["f32", "bf16", "f16"][int(rng.integers(0, 3))]
+    alg = ["FedAvg", "FedAvgM", "FedAdam", "FedYogi", "FedAdagrad"][int(rng.integers(0, 5))]
+    n = int(rng.choice([5, 1003, 70_001, 600_003]))
+    spec = _spec(kind, n)
+    cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode=str(rng.choice(["sample_size", "equal"])))
+    agg = ShardedFedAvgAggregator(None, cfg, None, algorithm=alg, pieces=int(rng.choice([1, 2, 3, 7])), mode=mode)
+    ora = OA.ORACLES[alg + "Aggregator"](None, cfg, None)
+    for a in (agg, ora):
+        for c in range(6):
+            a.set_client_sample_size(c, 3 + 2 * c)
+    for r in range(4):
+        K = int(rng.integers(1, 6))
+        ids = [int(c) for c in rng.permutation(6)[:K]]
+        models = {c: S.make_state(spec, seed=100_000 * seed + 100 * r + c, huge=False) for c in ids}
+        if K > 1 and r and rng.random() < 0.3:
+            del models[ids[-1]]["v"]
+        what = f"seed {seed} {alg} {mode} {kind} n={n} round {r}: clients {ids}"
+        for c in ids[:int(rng.integers(0, K + 1))]:
+            agg.stage(c, models[c])
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        _same(got, want, what)
+        if rng.random() < 0.5:
+            _same(agg.get_parameters(), want, what + " (served)")
+    if alg != "FedAvg":
+        m, v = agg.gather_moments()
+        _same({k: t.cpu() for k, t in v.items()}, ora.v_vector, "v")
