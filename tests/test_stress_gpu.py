@@ -210,3 +210,47 @@ def test_random_rounds_of_the_sharded_class_on_one_rank(seed):
     if alg != "FedAvg":
         m, v = agg.gather_moments()
         _same({k: t.cpu() for k, t in v.items()}, ora.v_vector, "v")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_fedcompass_and_fedqueue_sequences(seed):
+    """Single arrivals and groups in random order (FedCompass), groups of changing membership
+    (FedQueue), random staleness and sizes, fp32 / bf16 / f16: every reply against the oracle."""
+    import appfl_amd.aggregator as A
+    rng = np.random.default_rng(5000 + seed + SEED_OFFSET)
+    kind = ["f32", "bf16", "f16"][int(rng.integers(0, 3))]
+    cls = ["FedCompassAggregator", "FedQueueAggregator"][int(rng.integers(0, 2))]
+    n = int(rng.choice([5, 1003, 70_001, 600_003]))
+    spec = _spec(kind, n)
+    gb = bool(rng.integers(0, 2))
+    if cls == "FedCompassAggregator":
+        stale = dict(list(S.STALENESS.values())[int(rng.integers(0, len(S.STALENESS)))])
+        cfg = dict(stale, alpha=float(rng.choice([0.9, 0.5])), num_clients=5, gradient_based=gb)
+    else:
+        cfg = [{"staleness_fn": "harmonic", "staleness_fn_kwargs": {"beta": 0.5}, "gradient_based": gb},
+               {"gradient_based": gb}][int(rng.integers(0, 2))]
+    agg, ora = getattr(A, cls)(None, cfg, None), OA.ORACLES[cls](None, cfg, None)
+    if rng.random() < 0.6:
+        for a in (agg, ora):
+            for c in range(5):
+                a.set_client_sample_size(c, 3 + 2 * c)
+    for it in range(8):
+        K = int(rng.integers(1, 5))
+        ids = [int(c) for c in rng.permutation(5)[:K]]
+        what = f"seed {seed} {cls} {kind} n={n} cfg={cfg} step {it}: clients {ids}"
+        models = {c: S.make_state(spec, seed=100_000 * seed + 100 * it + c, huge=False, gradient=gb) for c in ids}
+        stale_of = {c: int(rng.integers(0, 6)) for c in ids}
+        copies = {c: {k: v.clone() for k, v in m.items()} for c, m in models.items()}
+        if cls == "FedCompassAggregator" and rng.random() < 0.5:
+            c = ids[0]
+            got = agg.aggregate(client_id=c, local_model=models[c], staleness=stale_of[c])
+            want = ora.aggregate(client_id=c, local_model=copies[c], staleness=stale_of[c])
+        elif cls == "FedCompassAggregator":
+            got = agg.aggregate(local_models=models, staleness=stale_of)
+            want = ora.aggregate(local_models=copies, staleness=stale_of)
+        else:
+            got = agg.aggregate(models, stale_of)
+            want = ora.aggregate(copies, stale_of)
+        _same(got, want, what)
+        if rng.random() < 0.3:
+            _same(agg.get_parameters(), ora.get_parameters(), what + " (served)")
