@@ -254,3 +254,23 @@ def test_random_fedcompass_and_fedqueue_sequences(seed):
         _same(got, want, what)
         if rng.random() < 0.3:
             _same(agg.get_parameters(), ora.get_parameters(), what + " (served)")
+
+
+@pytest.mark.parametrize("staged", ["all", "all_but_last"])
+def test_more_clients_than_one_launch_takes_through_the_staged_paths(staged):
+    """130 clients of a model above the pipelines' threshold: the folding on arrival, the
+    pipelined last arrival and the plain round all carry the partial step across launches."""
+    import appfl_amd.aggregator as A
+    from appfl_amd import ops
+    K = ops.kchunk() + 2
+    spec = {"w": ((4_200_001,), "f32"), "steps": ((), "i64")}
+    cfg = dict(S.HP["FedAdamAggregator"], client_weights_mode="equal", num_clients=K)
+    agg, ora = A.FedAdamAggregator(None, cfg, None), OA.OracleFedAdam(None, cfg, None)
+    for r in range(1):       # (the un-staged round of so many clients runs in tests/test_aggregators_gpu.py)
+        models = {c: S.make_state(spec, seed=1000 * r + c, huge=False) for c in range(K)}
+        n_staged = {"all": K, "all_but_last": K - 1}[staged]
+        for c in range(n_staged):
+            agg.stage(c, models[c])
+        got = agg.aggregate(models)
+        want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
+        _same(got, want, (staged, r))
