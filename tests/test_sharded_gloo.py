@@ -714,3 +714,75 @@ def test_streamed_rounds_of_a_16_bit_model_on_two_ranks(tmp_path):
         assert list(rec) == list(want), i
         for k in want:
             assert golden_util.same_bits(rec[k], want[k]), (i, k)
+
+
+# -- random rounds on several ranks --------------------------------------------------------------------
+
+def _random_plan(seed):
+    """What every rank and the checker derive alike from the seed."""
+    rng = np.random.default_rng(40 + seed)
+    kind = ["f32", "bf16", "f16"][int(rng.integers(0, 3))]
+    alg = ["FedAvg", "FedAvgM", "FedAdam", "FedYogi", "FedAdagrad"][int(rng.integers(0, 5))]
+    n = int(rng.choice([3, 61, 1003, 20_011]))
+    spec = {"w": ((n,), kind), "steps": ((3,), "i64"), "b": ((7, 3), kind), "c32": ((5,), "i32"),
+            "v": ((n // 3 + 1,), kind)}
+    pieces = int(rng.choice([1, 2, 5]))
+    mode = str(rng.choice(["sample_size", "equal"]))
+    rounds = []
+    for r in range(4):
+        K = int(rng.integers(1, 6))
+        ids = [int(c) for c in rng.permutation(6)[:K]]
+        rounds.append((ids, int(rng.integers(0, K + 1)), bool(K > 1 and r and rng.random() < 0.3)))
+    return kind, alg, spec, pieces, mode, rounds
+
+
+def _random_clients(spec, seed, r, ids, drop):
+    import scenarios as S
+    models = {c: S.make_state(spec, seed=10_000 * seed + 100 * r + c, huge=False) for c in ids}
+    if drop:
+        del models[ids[-1]]["v"]
+    return models
+
+
+def _random_worker(rank, world, port, seed, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        kind, alg, spec, pieces, mode, rounds = _random_plan(seed)
+        cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode=mode)
+        agg = ShardedFedAvgAggregator(None, cfg, None, algorithm=alg, device="cpu", backend=cpu_backend,
+                                      pieces=pieces)
+        for c in range(6):
+            agg.set_client_sample_size(c, 3 + 2 * c)
+        recs = []
+        for r, (ids, n_staged, drop) in enumerate(rounds):
+            models = _random_clients(spec, seed, r, ids, drop)
+            for c in ids[:n_staged]:
+                agg.stage(c, models[c])
+            recs.append(S._snap(agg.aggregate(models)))
+        if rank == world - 1:
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed,world", [(0, 2), (1, 3), (2, 2), (3, 3)])
+def test_random_sliced_rounds_on_several_ranks(seed, world, tmp_path):
+    import golden_util
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_random_worker, args=(world, _free_port(), seed, out), nprocs=world, join=True)
+    got = list(np.load(out, allow_pickle=True))
+    kind, alg, spec, pieces, mode, rounds = _random_plan(seed)
+    ora = OA.ORACLES[alg + "Aggregator"](None, dict(S.HP[alg + "Aggregator"], client_weights_mode=mode), None)
+    for c in range(6):
+        ora.set_client_sample_size(c, 3 + 2 * c)
+    for r, (ids, n_staged, drop) in enumerate(rounds):
+        want = S._snap(ora.aggregate(_random_clients(spec, seed, r, ids, drop)))
+        assert list(got[r]) == list(want), (seed, r)
+        for k in want:
+            assert golden_util.same_bits(got[r][k], want[k]), (seed, kind, alg, pieces, r, k)
