@@ -786,3 +786,79 @@ def test_random_sliced_rounds_on_several_ranks(seed, world, tmp_path):
         assert list(got[r]) == list(want), (seed, r)
         for k in want:
             assert golden_util.same_bits(got[r][k], want[k]), (seed, kind, alg, pieces, r, k)
+
+
+def _random_whole_plan(seed):
+    rng = np.random.default_rng(140 + seed)
+    alg = ["FedAvg", "FedAvgM", "FedAdam", "FedYogi"][int(rng.integers(0, 4))]
+    n = int(rng.choice([3, 61, 1003, 20_011]))
+    spec = {"w": ((n,), "f32"), "steps": ((3,), "i64"), "b": ((7, 3), "f32"), "c32": ((5,), "i32"),
+            "v": ((n // 3 + 1,), "f32"), "d": ((4,), "f64")}
+    pieces = int(rng.choice([1, 2, 5]))
+    mode = str(rng.choice(["sample_size", "equal"]))
+    unsized = int(rng.integers(0, 7))          # a client without a recorded sample size (6: none)
+    rounds = []
+    for r in range(4):
+        K = int(rng.integers(1, 7))
+        rounds.append((K, bool(rng.integers(0, 2)), bool(K > 1 and r and rng.random() < 0.3)))
+    return alg, spec, pieces, mode, unsized, rounds
+
+
+def _random_whole_clients(spec, seed, r, K, drop):
+    import scenarios as S
+    models = {c: S.make_state(spec, seed=20_000 * seed + 100 * r + c, huge=False) for c in range(K)}
+    if drop:
+        del models[K - 1]["v"]
+    return models
+
+
+def _random_whole_worker(rank, world, port, seed, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cpu_backend
+        import scenarios as S
+        from appfl_amd.aggregator.sharded_aggregator import ShardedFedAvgAggregator
+        alg, spec, pieces, mode, unsized, rounds = _random_whole_plan(seed)
+        cfg = dict(S.HP[alg + "Aggregator"], client_weights_mode=mode)
+        agg = ShardedFedAvgAggregator(None, cfg, None, algorithm=alg, device="cpu", backend=cpu_backend,
+                                      pieces=pieces, mode="whole")
+        for c in range(6):
+            if c != unsized:
+                agg.set_client_sample_size(c, 3 + 2 * c)
+        recs = []
+        for r, (K, staged, drop) in enumerate(rounds):
+            models = _random_whole_clients(spec, seed, r, K, drop)
+            mine = {c: models[c] for c in models if c % world == rank}      # client k -> rank k mod R
+            if staged:
+                for c, m in mine.items():
+                    agg.stage(c, m)
+            recs.append({k: v.numpy().copy() for k, v in agg.aggregate(mine).items()})
+        if rank == world - 1:
+            np.save(out, np.array(recs, dtype=object), allow_pickle=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed,world", [(0, 2), (1, 3), (2, 3), (3, 2)])
+def test_random_whole_update_rounds_on_several_ranks(seed, world, tmp_path):
+    import scenarios as S
+    from oracle import aggregators as OA
+    out = str(tmp_path / "recs.npy")
+    mp.spawn(_random_whole_worker, args=(world, _free_port(), seed, out), nprocs=world, join=True)
+    got = list(np.load(out, allow_pickle=True))
+    alg, spec, pieces, mode, unsized, rounds = _random_whole_plan(seed)
+    ora = OA.ORACLES[alg + "Aggregator"](None, dict(S.HP[alg + "Aggregator"], client_weights_mode=mode), None)
+    for c in range(6):
+        if c != unsized:
+            ora.set_client_sample_size(c, 3 + 2 * c)
+    for r, (K, staged, drop) in enumerate(rounds):
+        want = ora.aggregate(_random_whole_clients(spec, seed, r, K, drop))
+        assert list(got[r]) == list(want), (seed, r)
+        for k in want:
+            w = np.asarray(want[k])
+            assert got[r][k].dtype == w.dtype and got[r][k].shape == w.shape, (seed, r, k)
+            if w.dtype == np.float32:      # no model: every fp32 entry is weighted -- the sum is reordered
+                assert _close(got[r][k], w, 1e-6 * (r + 1)), (seed, alg, pieces, r, k)
+            else:
+                assert got[r][k].tobytes() == w.tobytes(), (seed, alg, pieces, r, k)
