@@ -586,3 +586,64 @@ def test_16_bit_fedasync_pipelined_arrival_and_fedbuff_early_download(kind, grad
         got = early.aggregate(i % 3, {k: v.clone() for k, v in st.items()})
         want = orab.aggregate(i % 3, {k: v.clone() for k, v in st.items()})
         _same_records(got, want, (kind, "buff", i))
+
+
+def test_the_16_bit_entry_points_refuse_bad_arguments_with_their_error_codes():
+    """Straight through the C ABI: NULL buffers, unknown type / optimizer codes, no clients, odd
+    addresses, a client list longer than one launch without a workspace -- each answered with
+    the documented code before anything is launched (the buffers keep their contents)."""
+    import ctypes as C
+
+    from appfl_amd import _native as N
+    lib = N.load()
+    INVALID, ALIGN, WORKSPACE = -1, -2, -3
+    n, K = 64, 3
+    g = torch.full((n,), 1.5, dtype=torch.bfloat16, device="cuda")
+    m, v, step = torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(g)
+    xs = [torch.full((n,), float(k), dtype=torch.bfloat16, device="cuda") for k in range(K)]
+    x, w = N.ptr_array([t.data_ptr() for t in xs]), N.double_array([1.0 / K] * K)
+    P = lambda t: C.c_void_p(t.data_ptr())                      # noqa: E731
+    BF = N.FA_HALF_BF16
+    adam = (0.1, 0.9, 0.99, 1e-3)
+
+    def reduce_opt(x_=x, w_=w, K_=K, g_=P(g), m_=P(m), v_=P(v), opt=2, step_out=None, ws=None, half=BF):
+        return lib.fa_half_reduce_opt(x_, w_, K_, g_, m_, v_, n, opt, *adam, step_out, ws, half, None)
+
+    assert reduce_opt() == 0
+    torch.cuda.synchronize()
+    before = g.clone()
+    assert reduce_opt(x_=None) == INVALID and reduce_opt(w_=None) == INVALID and reduce_opt(g_=None) == INVALID
+    assert reduce_opt(K_=0) == INVALID and reduce_opt(half=7) == INVALID and reduce_opt(opt=9) == INVALID
+    assert reduce_opt(v_=None) == INVALID and reduce_opt(m_=None) == INVALID         # the moments Adam needs
+    assert reduce_opt(g_=C.c_void_p(g.data_ptr() + 1)) == ALIGN
+    odd = N.ptr_array([xs[0].data_ptr(), xs[1].data_ptr() + 1, xs[2].data_ptr()])
+    assert reduce_opt(x_=odd) == ALIGN
+    holes = N.ptr_array([xs[0].data_ptr(), 0, xs[2].data_ptr()])
+    assert reduce_opt(x_=holes) == INVALID
+    from appfl_amd import ops
+    many = ops.kchunk() + 1
+    xm, wm = N.ptr_array([xs[0].data_ptr()] * many), N.double_array([1.0 / many] * many)
+    assert reduce_opt(x_=xm, w_=wm, K_=many) == WORKSPACE
+    assert reduce_opt(x_=xm, w_=wm, K_=many, ws=P(step)) == 0
+    torch.cuda.synchronize()
+    g.copy_(before)
+    # the other entry points
+    assert lib.fa_half_reduce_step_resume(x, w, K, K, P(g), P(step), n, BF, None) == INVALID    # no client left
+    assert lib.fa_half_reduce_step_resume(x, w, K, -1, P(g), P(step), n, BF, None) == INVALID
+    assert lib.fa_half_reduce_opt_resume(x, w, K, 1, P(g), P(m), P(v), n, 2, *adam, None, BF, None) == WORKSPACE
+    assert lib.fa_half_server_opt_step(P(step), None, P(v), n, 2, *adam, BF, None) == INVALID
+    assert lib.fa_half_server_opt_step(P(step), P(m), P(v), n, 0, *adam, BF, None) == 0          # nothing to do
+    assert lib.fa_half_apply_step(None, P(step), n, BF, None) == INVALID
+    assert lib.fa_half_mean(x, 0, P(g), n, BF, None) == INVALID
+    assert lib.fa_half_weighted_mix(x, w, K, P(g), 0.5, 9, None, n, BF, None) == INVALID         # unknown mode
+    assert lib.fa_half_weighted_mix(x, w, K, P(g), 0.5, 3, None, n, BF, None) == INVALID         # convex_one: K = 1
+    assert lib.fa_half_weighted_mix(xm, wm, many, P(g), 0.5, 1, None, n, BF, None) == WORKSPACE
+    assert lib.fa_half_async_mix(None, 0.5, 0, 0, P(g), None, n, BF, None) == INVALID
+    assert lib.fa_half_async_mix(P(xs[0]), 0.5, 0, 0, C.c_void_p(g.data_ptr() + 1), None, n, BF, None) == ALIGN
+    assert lib.fa_half_buff_accum(P(xs[0]), 0.5, 0, P(g), None, 1, 0, n, BF, None) == INVALID
+    assert lib.fa_half_buff_flush_mean(P(g), P(step), 0, n, BF, None) == INVALID
+    assert lib.fa_half_fill(P(g), 1.0, n, 0, None) == INVALID
+    torch.cuda.synchronize()
+    assert torch.equal(g.view(torch.int16), before.view(torch.int16))
+    # n = 0 is a valid empty call everywhere
+    assert lib.fa_half_mean(x, K, P(g), 0, BF, None) == 0 and lib.fa_half_fill(P(g), 1.0, 0, BF, None) == 0
