@@ -970,3 +970,57 @@ def test_round_plan_launches_equal_marshalled_rounds():
     for a, b in ((g1, g2), (m1, m2), (v1, v2)):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     del plan
+
+
+def test_the_entry_points_refuse_bad_arguments_with_their_error_codes():
+    """Straight through the C ABI (fp32 entry points): NULL buffers, unknown optimizer / mode /
+    flag codes, no clients, misaligned addresses, a client list longer than one launch without
+    a workspace, a split without one -- each answered with the documented code before anything
+    is launched (the buffers keep their contents)."""
+    import ctypes as C
+
+    from appfl_amd import _native as N
+    from appfl_amd import ops
+    lib = N.load()
+    INVALID, ALIGN, WORKSPACE = -1, -2, -3
+    n, K = 64, 3
+    g = torch.full((n,), 1.5, dtype=torch.float32, device="cuda")
+    m, v, step = torch.zeros_like(g), torch.zeros_like(g), torch.zeros_like(g)
+    xs = [torch.full((n,), float(k), dtype=torch.float32, device="cuda") for k in range(K)]
+    x, w = N.ptr_array([t.data_ptr() for t in xs]), N.double_array([1.0 / K] * K)
+    P = lambda t: C.c_void_p(t.data_ptr())                      # noqa: E731
+    adam = (0.1, 0.9, 0.99, 1e-3)
+
+    def reduce_opt(x_=x, w_=w, K_=K, g_=P(g), m_=P(m), v_=P(v), opt=2, step_out=None, ws=None):
+        return lib.fa_reduce_opt(x_, w_, K_, g_, m_, v_, n, opt, *adam, step_out, ws, None)
+
+    assert reduce_opt() == 0
+    torch.cuda.synchronize()
+    before = g.clone()
+    assert reduce_opt(x_=None) == INVALID and reduce_opt(w_=None) == INVALID and reduce_opt(g_=None) == INVALID
+    assert reduce_opt(K_=0) == INVALID and reduce_opt(opt=9) == INVALID and reduce_opt(opt=-1) == INVALID
+    assert reduce_opt(v_=None) == INVALID and reduce_opt(m_=None) == INVALID
+    assert reduce_opt(g_=C.c_void_p(g.data_ptr() + 2)) == ALIGN
+    assert reduce_opt(x_=N.ptr_array([xs[0].data_ptr(), xs[1].data_ptr() + 1, xs[2].data_ptr()])) == ALIGN
+    assert reduce_opt(x_=N.ptr_array([xs[0].data_ptr(), 0, xs[2].data_ptr()])) == INVALID
+    many = ops.kchunk() + 1
+    xm, wm = N.ptr_array([xs[0].data_ptr()] * many), N.double_array([1.0 / many] * many)
+    assert reduce_opt(x_=xm, w_=wm, K_=many) == WORKSPACE
+    assert lib.fa_reduce_opt_ex(x, w, K, P(g), P(m), P(v), n, 2, *adam, None, None, 8, None) == INVALID   # unknown flag
+    assert lib.fa_round(x, w, K, P(g), P(m), P(v), n, 2, *adam, None, None, None, 0, 1, None, None) == WORKSPACE  # a split
+    assert lib.fa_round(x, w, K, P(g), P(m), P(v), n, 2, *adam, None, None, None, 0, K + 1, None, None) == INVALID
+    assert lib.fa_reduce_step_resume(x, w, K, K, P(g), P(step), n, None) == INVALID                   # no client left
+    assert lib.fa_round_resume(x, w, K, 1, P(g), P(m), P(v), n, 2, *adam, None, None, 0, None) == WORKSPACE
+    assert lib.fa_server_opt_step(P(step), None, P(v), n, 2, *adam, None) == INVALID
+    assert lib.fa_apply_step(None, P(step), n, None) == INVALID
+    assert lib.fa_mean_f32(x, 0, P(g), n, None) == INVALID
+    assert lib.fa_weighted_mix(x, w, K, P(g), 0.5, 9, None, n, None) == INVALID                        # unknown mode
+    assert lib.fa_weighted_mix(x, w, K, P(g), 0.5, 3, None, n, None) == INVALID                        # convex_one: K = 1
+    assert lib.fa_weighted_mix(xm, wm, many, P(g), 0.5, 1, None, n, None) == WORKSPACE
+    assert lib.fa_async_mix(None, 0.5, 0, 0, P(g), None, n, None) == INVALID
+    assert lib.fa_async_mix(P(xs[0]), 0.5, 0, 0, C.c_void_p(g.data_ptr() + 2), None, n, None) == ALIGN
+    assert lib.fa_buff_accum(P(xs[0]), 0.5, 0, P(g), None, 1, n, None) == INVALID
+    torch.cuda.synchronize()
+    assert torch.equal(g, before)
+    assert lib.fa_mean_f32(x, K, P(g), 0, None) == 0          # n = 0: a valid empty call
+    assert b"workspace" in lib.fa_error_string(WORKSPACE).lower() or lib.fa_error_string(WORKSPACE)
