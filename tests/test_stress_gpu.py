@@ -65,6 +65,12 @@ def test_random_staged_rounds(seed, monkeypatch):
             agg.stage(c, models[c])
         if order and rng.random() < 0.25:
             agg.stage(order[0], models[order[0]])        # the same client again
+        if order and rng.random() < 0.2:
+            # a staged client sends again and the scheduler's dict holds the new message, which
+            # was never staged: the round must take the dict's
+            c = order[int(rng.integers(0, len(order)))]
+            models[c] = S.make_state(spec, seed=100_000 * seed + 100 * r + c + 50, huge=False)
+            what += f", client {c} replaced un-staged"
         got = agg.aggregate(models)
         want = ora.aggregate({c: {k: v.clone() for k, v in m.items()} for c, m in models.items()})
         _same(got, want, what)
