@@ -16,11 +16,13 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
 
 #include "../../include/appfl_amd.h"
+#include "internal.h"
 
 namespace {
 
@@ -31,6 +33,8 @@ constexpr int kMaxBlocks = 1 << 20;
 constexpr int kAhead = 8;   // client loads in flight per element / vector
 constexpr int kWide = 8;    // elements of a 128-bit load
 constexpr size_t kSegmentH = size_t(1) << 30;   // elements one reduce launch covers at most
+
+#include "grid_meet.h"
 
 // Launch shape of the 128-bit reduce kernel: vectors per thread and client loads in flight per
 // vector (build-time knobs for A/B runs; the defaults are the measured best).  ResNet-50 x 64
@@ -285,6 +289,9 @@ struct ReduceHArgs {
     size_t n;   // elements of width VEC
     int K, last, apply;
     HyperH h;
+    unsigned* sync_word;   // late-epilogue kernel: the counter its blocks meet on (NULL: no meetings)
+    unsigned sync_epoch;   // ... and this launch's tag in it
+    int sync_groups;       // 2: the odd and the even XCDs' blocks meet apart, half a phase shifted; 1: all together
 };
 
 // One block walks tiles of kThreads * VPT elements of width VEC; thread t owns elements
@@ -385,6 +392,218 @@ __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent variant with a LATE optimizer epilogue (the 16-bit counterpart of the fp32 library's
+// kernel of that kind): one block per CU takes every gridDim.x-th tile of 256 x 4 vectors, folds
+// its clients into the averaged step alone -- 8 clients x 4 vectors = 32 packed 128-bit loads in
+// flight per lane at one wave per SIMD --, parks the step (16 bits per element) in LDS and, every
+// kLateTiles tiles, runs the epilogue over the parked tiles: g (for the second time), m and v are
+// read, the optimizer formulas evaluated, g, m and v written.  A phase is a long stretch of pure
+// reads followed by a copy-like burst instead of three thin result streams among the reads.
+// Same operations on the same values in the same order as reduce_half_kernel: same bits.
+#ifndef FA_HALF_LATE_TILES
+#define FA_HALF_LATE_TILES 10
+#endif
+#ifndef FA_HALF_LATE_AHEAD
+#define FA_HALF_LATE_AHEAD 2
+#endif
+constexpr int kLateTiles = FA_HALF_LATE_TILES;
+#ifndef FA_HALF_LATE_VPT
+#define FA_HALF_LATE_VPT 4
+#endif
+constexpr int kLateVpt = FA_HALF_LATE_VPT;
+
+template <int OPT, int HALF>
+__global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const ReduceHArgs a) {
+    static_assert(OPT != FA_OPT_NONE, "plain FedAvg has no epilogue to defer");
+    constexpr int VPT = kLateVpt, U = FA_HALF_LATE_AHEAD, P = kLateTiles, VEC = kWide;
+    constexpr bool kHasM = OPT >= FA_OPT_ADAM;
+    __shared__ u4 stash[P][VPT][kThreads];
+    const unsigned G = gridDim.x, n = static_cast<unsigned>(a.n);
+    const unsigned per_round = G * kThreads * VPT;
+    const unsigned rounds = (n + per_round - 1) / per_round;
+    const unsigned slots = G * rounds;
+    const unsigned tlen = (((n + slots - 1) / slots) + 63u) & ~63u;     // equal-length tiles, whole wave rows
+    const unsigned total = (n + tlen - 1) / tlen;
+    unsigned slot = blockIdx.x;
+    if (G % 8 == 0) slot = (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;  // an XCD's blocks take neighbouring tiles
+    // chip-wide phases: the blocks meet before their bursts (timing only, bounded waits), the odd
+    // and the even XCDs' blocks as two groups half a phase apart
+    const unsigned most = (total + G - 1) / G;
+    bool phased = a.sync_word != nullptr && most > static_cast<unsigned>(P);
+    GridMeet meet = {a.sync_word, 0u, false, G};
+    unsigned shift = 0, meetings = 0;
+    if (phased && a.sync_groups == 2 && G % 8 == 0) {
+        const unsigned group = (blockIdx.x % 8u) % 2u;
+        meet.word = a.sync_word + 4u * group;
+        meet.blocks = G / 2u;
+        shift = group * P / 2u;
+    }
+    if (phased) {
+        meetings = (most + shift + P - 1) / P;
+        grid_meet_enter(meet, a.sync_epoch);
+    }
+    if (slot >= total) {
+        if (phased) grid_meet_leave(meet, meetings);
+        return;
+    }
+    const unsigned ntiles = (total - slot + G - 1) / G;
+    const unsigned r0 = slot * tlen, tstride = G * tlen;
+    auto index = [&](unsigned tile, int p, bool& live) -> unsigned {
+        const unsigned off = p * kThreads + threadIdx.x;
+        const unsigned i = r0 + tile * tstride + off;
+        live = off < tlen && i < n;
+        return live ? i : n - 1;      // idle lanes redo the last vector, never store
+    };
+    // The client loop runs in batches of U clients, double-buffered: the loads of batch b + 1 are
+    // in flight while batch b is folded, and the first batch (and g) of the NEXT tile is requested
+    // before this tile's step is parked and the epilogue runs -- at one wave per SIMD nothing
+    // else would hide the memory latency at a tile's start.
+    unsigned idx[VPT], idn[VPT];
+    Raw<VEC> gr[VPT], xa[U][VPT], xb[U][VPT];
+    auto request = [&](int k0, Raw<VEC> (&buf)[U][VPT], const unsigned (&ix)[VPT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) buf[u][p] = load_raw<VEC, true>(a.x[k0 + u], ix[p]);
+    };
+    const int nb = a.K / U;
+#pragma unroll
+    for (int p = 0; p < VPT; ++p) {
+        bool live;
+        idx[p] = index(0, p, live);
+        gr[p] = load_raw<VEC, false>(a.g, idx[p]);
+    }
+    if (nb > 0) request(0, xa, idx);
+    for (unsigned ct = 0; ct < ntiles; ++ct) {
+        PackH<VEC> g[VPT], s[VPT];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            g[p] = widen<HALF, VEC>(gr[p]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s[p].e[e] = 0.0f;
+        }
+        auto fold = [&](int k0, const Raw<VEC> (&buf)[U][VPT]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w = a.w[k0 + u];
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) {
+                    const PackH<VEC> x = widen<HALF, VEC>(buf[u][p]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float d = rnd<HALF>(x.e[e] - g[p].e[e]);
+                        float wd = rnd<HALF>(d * w);
+                        s[p].e[e] = rnd<HALF>(s[p].e[e] + wd);
+                    }
+                }
+            }
+        };
+        int b = 0;
+#pragma unroll 1
+        for (; b + 2 <= nb; b += 2) {
+            request((b + 1) * U, xb, idx);
+            fold(b * U, xa);
+            if (b + 2 < nb) request((b + 2) * U, xa, idx);
+            fold((b + 1) * U, xb);
+        }
+        if (b < nb) fold(b * U, xa);
+        for (int k = nb * U; k < a.K; ++k) {
+            const float w = a.w[k];
+            Raw<VEC> xr[VPT];
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) xr[p] = load_raw<VEC, true>(a.x[k], idx[p]);
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) {
+                const PackH<VEC> x = widen<HALF, VEC>(xr[p]);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float d = rnd<HALF>(x.e[e] - g[p].e[e]);
+                    float wd = rnd<HALF>(d * w);
+                    s[p].e[e] = rnd<HALF>(s[p].e[e] + wd);
+                }
+            }
+        }
+        if (ct + 1 < ntiles) {
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) {
+                bool live;
+                idn[p] = index(ct + 1, p, live);
+                gr[p] = load_raw<VEC, false>(a.g, idn[p]);
+            }
+            if (nb > 0) request(0, xa, idn);
+        }
+        const int j = static_cast<int>((ct + shift) % P);
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            u4 t;
+            t.x = narrow2<HALF>(s[p].e[0], s[p].e[1]);
+            t.y = narrow2<HALF>(s[p].e[2], s[p].e[3]);
+            t.z = narrow2<HALF>(s[p].e[4], s[p].e[5]);
+            t.w = narrow2<HALF>(s[p].e[6], s[p].e[7]);
+            stash[j][p][threadIdx.x] = t;       // every thread only touches its own slots: no barrier
+        }
+        if (j == P - 1 || ct + 1 == ntiles) {
+            const unsigned first = ct - static_cast<unsigned>(j);
+            const int j_lo = (ct < static_cast<unsigned>(P) && static_cast<unsigned>(j) >= ct) ? j - static_cast<int>(ct) : 0;
+            if (phased) grid_meet(meet);
+            // the epilogue over the parked tiles: all of a tile's g / m / v loads are issued at
+            // once, the next tile's fly while this tile's formulas are evaluated and stored
+            Raw<VEC> gq[2][VPT], mq[2][VPT], vq[2][VPT];
+            auto fetch = [&](int jj, int b) {
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) {
+                    bool live;
+                    const unsigned i = index(first + jj, p, live);
+                    gq[b][p] = load_raw<VEC, false>(a.g, i);
+                    vq[b][p] = load_raw<VEC, true>(a.v, i);
+                    if (kHasM) mq[b][p] = load_raw<VEC, true>(a.m, i);
+                }
+            };
+            auto finish = [&](int jj, int b) {
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) {
+                    bool live;
+                    const unsigned i = index(first + jj, p, live);
+                    Raw<VEC> sr;
+                    sr.v = stash[jj][p][threadIdx.x];
+                    PackH<VEC> st = widen<HALF, VEC>(sr), gg = widen<HALF, VEC>(gq[b][p]), vv = widen<HALF, VEC>(vq[b][p]), mm;
+                    if (kHasM) {
+                        mm = widen<HALF, VEC>(mq[b][p]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) mm.e[e] = 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float step = optimizer_step_h<OPT, HALF>(st.e[e], mm.e[e], vv.e[e], a.h);
+                        gg.e[e] = rnd<HALF>(gg.e[e] + step);
+                    }
+                    if (live) {
+                        store_result_h<HALF, VEC>(a.v, i, vv);
+                        if (kHasM) store_result_h<HALF, VEC>(a.m, i, mm);
+                        store_result_h<HALF, VEC>(a.g, i, gg);
+                    }
+                }
+            };
+            fetch(j_lo, 0);
+#pragma unroll 1
+            for (int jj = j_lo; jj <= j; jj += 2) {
+                if (jj + 1 <= j) fetch(jj + 1, 1);
+                finish(jj, 0);
+                if (jj + 1 <= j) {
+                    if (jj + 2 <= j) fetch(jj + 2, 0);
+                    finish(jj + 1, 1);
+                }
+            }
+            if (phased) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the burst before the next phase's loads
+        }
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) idx[p] = idn[p];
+    }
+    if (phased) grid_meet_leave(meet, meetings);
 }
 
 template <int OPT, int HALF>
@@ -595,8 +814,60 @@ HyperH make_hyper_h(double lr, double beta1, double beta2, double tau, int half)
                   rnd_host(static_cast<float>(tau), half)};
 }
 
+// Benchmark knob of the persistent kernel with the late epilogue, read at every launch:
+// APPFL_AMD_HALF_LATE = 0 keeps every round on the tile-per-block kernel, 1 (the default) routes
+// to the late-epilogue kernel where it applies, with the odd and the even XCDs' blocks meeting
+// as two staggered groups, 2 the same without meetings, 3 with one chip-wide group; 4 forces the
+// kernel at every client count and length it can run on.  Same bits whatever the value.
+int late_mode() {
+    const char* e = getenv("APPFL_AMD_HALF_LATE");
+    return e && *e ? atoi(e) : 1;
+}
+
+// Where the late-epilogue kernel is ahead of the tile-per-block kernel (same process, kernel time,
+// bfloat16, tools/half_late_sweep.py, profiles/r03_half_late_sweep.log; `tiles` = tiles of 256 x 4 vectors per CU).  Two-moment
+// optimizers: 8 M elements (3.8 tiles) x 48 / 64 / 100 clients -3.7 / -5.5 / -9.6 %, 25.6 M (12 tiles)
+// x 32 / 48 / 64 / 100 -1.1 / -7.0 / -8.9 / -10.6 %, 47 M (22 tiles) x 24 / 32 / 64 -1.0 / -5.2 / -9.7 %,
+// 162.5 M x 24 / 32 -4.1 / -5.4 %; behind at fewer clients (25.6 M x 24 / 16 / 8 +4 / +17 / +42 %:
+// at one wave per SIMD a short client list leaves the epilogue nothing to hide behind) and on
+// short vectors (4.5 M x 48 +8 %).  FedAvgM (two result streams): from 32 clients at 3.5 tiles
+// (8 M x 32 / 64 -2.3 / -9.1 %), 24 at 12 (25.6 M -1.3 %), 16 at 40 (87 M -3.6 %).
+// float16 stays on the tile-per-block kernel at every shape: its roundings are two conversions
+// each (bfloat16: one instruction), and at one wave per SIMD that arithmetic has nothing to hide
+// behind -- 11.7-47 M elements x 8-100 clients +4...+42 % kernel time.
+bool late_wins(int half, int opt, int K, double tiles) {
+    if (half != FA_HALF_BF16) return false;
+    if (opt == FA_OPT_AVGM) return (K >= 32 && tiles >= 3.5) || (K >= 24 && tiles >= 12.0) || (K >= 16 && tiles >= 40.0);
+    return (K >= 48 && tiles >= 3.5) || (K >= 32 && tiles >= 12.0) || (K >= 24 && tiles >= 22.0);
+}
+
+// The late-epilogue kernel takes the final form of a launch (step, epilogue, apply; no carry in,
+// no step output) of an optimizer round.
+template <int HALF>
+bool launch_late_half(int opt, const ReduceHArgs& a0, hipStream_t st) {
+    const int mode = late_mode();
+    if (!mode || opt == FA_OPT_NONE || !a0.last || !a0.apply || a0.step_in || a0.step_out) return false;
+    const int G = fa_internal::cu_count();
+    if (mode != 4 && !late_wins(HALF, opt, a0.K, static_cast<double>(a0.n) / (static_cast<double>(G) * kThreads * kLateVpt)))
+        return false;
+    ReduceHArgs a = a0;
+    a.sync_word = mode == 2 ? nullptr : fa_internal::meeting_word(st, &a.sync_epoch);
+    a.sync_groups = mode == 3 ? 1 : 2;
+    const dim3 grid(G), block(kThreads);
+    switch (opt) {
+        case FA_OPT_AVGM: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_AVGM, HALF>), grid, block, 0, st, a); break;
+        case FA_OPT_ADAM: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_ADAM, HALF>), grid, block, 0, st, a); break;
+        case FA_OPT_YOGI: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_YOGI, HALF>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_ADAGRAD, HALF>), grid, block, 0, st, a); break;
+    }
+    return true;
+}
+
 template <int HALF, int VEC>
 void launch_reduce_half(int opt, const ReduceHArgs& a, hipStream_t st) {
+    if constexpr (VEC == kWide) {
+        if (launch_late_half<HALF>(opt, a, st)) return;
+    }
     constexpr int VPT = VEC == kWide ? FA_HALF_VPT : 1;
     constexpr int U = VEC == kWide ? FA_HALF_AHEAD : kAhead;
     const size_t tiles = (a.n + static_cast<size_t>(kThreads) * VPT - 1) / (static_cast<size_t>(kThreads) * VPT);
@@ -736,6 +1007,12 @@ int opt_step_half(void* step, void* m, void* v, size_t n, int opt, const HyperH&
 }  // namespace
 
 extern "C" {
+
+const char* fa_half_reduce_kernel_name(int K, size_t n, int opt, int half) {
+    if (K <= 0 || K > FA_KCHUNK || opt == FA_OPT_NONE || !late_mode()) return "reduce_half_kernel";
+    const double tiles = static_cast<double>(n / kWide) / (static_cast<double>(fa_internal::cu_count()) * kThreads * kLateVpt);
+    return (late_mode() == 4 || late_wins(half, opt, K, tiles)) ? "reduce_late_half_kernel" : "reduce_half_kernel";
+}
 
 float fa_half_round_scalar(double x, int half) {
     return known(half) ? rnd_host(static_cast<float>(x), half) : static_cast<float>(x);

@@ -33,6 +33,10 @@ class HalfOps:
 
     kchunk = staticmethod(ops.kchunk)
 
+    def reduce_kernel_name(self, K: int, n: int, opt: str = "none") -> str:
+        """Name of the kernel `reduce_opt` launches for K clients of n aligned 16-bit elements."""
+        return N.load().fa_half_reduce_kernel_name(K, n, OPT_CODES[opt], self.half).decode()
+
     def round_scalar(self, x: float) -> float:
         """`x` as the 16-bit type holds it (fa_half_round_scalar)."""
         return float(N.load().fa_half_round_scalar(float(x), self.half))

@@ -137,7 +137,9 @@ class SyncBench:
         if half is None:
             self.kernel = "%s<%s>" % (ops.reduce_kernel_name(self.K, self.n_step, self.opt), self.opt)
         else:
-            self.kernel = "reduce_half_kernel<%s,%s>" % (self.opt, str(half).split(".")[-1])
+            from appfl_amd import half_ops
+            self.kernel = "%s<%s,%s>" % (half_ops.HalfOps(half).reduce_kernel_name(self.K, self.n_step, self.opt),
+                                         self.opt, str(half).split(".")[-1])
         self.alg_bytes = item * (self.K + STATE_VECTORS[self.opt]) * self.n_step
         self.client_bytes = self.K * self.payload
         self.result_numel = lay.n_f32
@@ -408,6 +410,8 @@ def cpu_baseline(wl, budget_s):
 
     # fused C / OpenMP restatement on flat fp32 vectors of the same size
     n = W.numel([r for r in rows if r[2] == torch.float32])
+    if n == 0:      # a 16-bit workload: the C restatement is fp32 only
+        return naive_out, {"skipped": "the fused C restatement covers fp32 vectors only"}
     gf = np.concatenate([base[r[0]].numpy().ravel() for r in rows if r[2] == torch.float32])
     xs = [np.concatenate([clients[k][r[0]].numpy().ravel() for r in rows if r[2] == torch.float32])
           for k in range(Kc)]

@@ -77,7 +77,7 @@ def test_one_gpu_line_lists_every_benchmark_configuration():
     # the bfloat16 model moves 2-byte elements: half the algorithmic bytes of the fp32 one
     assert by_name["resnet50_fedadam_k64_bf16"]["algorithmic_bytes_per_launch"] * 2 == \
         by_name["resnet50_fedadam_k64"]["algorithmic_bytes_per_launch"]
-    assert by_name["resnet50_fedadam_k64_bf16"]["kernel"] == "reduce_half_kernel<adam,bfloat16>"
+    assert by_name["resnet50_fedadam_k64_bf16"]["kernel"] == "reduce_late_half_kernel<adam,bfloat16>"
     assert out["north_star_target"]["workload"] == "resnet50_fedadam_k64"
     assert out["north_star_target"]["frac"] == out["workloads"][0]["frac"]
     # cold-state figures (state vectors rotated over independent sets) beside the warm ones

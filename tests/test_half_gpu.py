@@ -647,3 +647,60 @@ def test_the_16_bit_entry_points_refuse_bad_arguments_with_their_error_codes():
     assert torch.equal(g.view(torch.int16), before.view(torch.int16))
     # n = 0 is a valid empty call everywhere
     assert lib.fa_half_mean(x, K, P(g), 0, BF, None) == 0 and lib.fa_half_fill(P(g), 1.0, 0, BF, None) == 0
+
+
+# -- the persistent kernel with the late epilogue ------------------------------------------------------
+
+def _late_rounds(o, dt, opt, K, n, shift, rounds=2):
+    gen = torch.Generator(device="cuda").manual_seed(n + K)
+    buf = lambda: torch.zeros(n + 16, dtype=dt, device="cuda")[shift:shift + n]     # noqa: E731
+    g = buf().copy_((torch.randn(n, device="cuda", generator=gen) * 0.05).to(dt))
+    m, v = buf(), buf()
+    if opt not in ("avgm",):
+        o.fill(v, 1e-6)
+    xs = [buf().copy_((g.float() + torch.randn(n, device="cuda", generator=gen) * 0.02).to(dt)) for _ in range(K)]
+    w = [(k + 1) / (K * (K + 1) / 2) for k in range(K)]
+    for _ in range(rounds):
+        o.reduce_opt(xs, w, g, None if opt == "avgm" else m, v, opt, lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
+    torch.cuda.synchronize()
+    return [t.clone().view(torch.int16) for t in (g, m, v)]
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("opt,K,n,shift", [("adam", 49, 3_000_011, 0), ("avgm", 33, 2_200_003, 8), ("yogi", 7, 700_001, 0),
+                                           ("adagrad", 128, 300_007, 0), ("adam", 3, 1_048_576, 0)])
+def test_late_epilogue_kernel_gives_the_bits_of_the_tile_kernel(kind, opt, K, n, shift, monkeypatch):
+    """The persistent kernel forced on shapes of every kind (client counts that leave a remainder
+    of the double-buffered batches, ragged lengths, a tile count that leaves CUs idle, buffers on
+    other 16-byte boundaries) against the tile-per-block kernel: g, m and v bit for bit."""
+    dt, o = KINDS[kind], _hops(kind)
+    monkeypatch.setenv("APPFL_AMD_HALF_LATE", "0")
+    want = _late_rounds(o, dt, opt, K, n, shift)
+    monkeypatch.setenv("APPFL_AMD_HALF_LATE", "4")
+    assert o.reduce_kernel_name(K, n, opt) == "reduce_late_half_kernel"
+    got = _late_rounds(o, dt, opt, K, n, shift)
+    for a, b, what in zip(got, want, "gmv"):
+        assert torch.equal(a, b), (kind, opt, K, n, what)
+
+
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
+def test_late_epilogue_kernel_in_phases_on_a_long_vector(mode, monkeypatch):
+    """ResNet-50 length x 48 clients: more tiles per CU than a phase holds, so the blocks meet
+    before their bursts (two staggered groups, no meetings, one chip-wide group): same bits,
+    and the default routing takes this kernel here."""
+    from appfl_amd import half_ops
+    dt, o = torch.bfloat16, _hops("bf16")
+    n, K = 25_557_032, 48
+    monkeypatch.delenv("APPFL_AMD_HALF_LATE", raising=False)
+    assert o.reduce_kernel_name(K, n, "adam") == "reduce_late_half_kernel"
+    assert o.reduce_kernel_name(16, n, "adam") == "reduce_half_kernel"
+    assert o.reduce_kernel_name(K, n, "none") == "reduce_half_kernel"
+    assert o.reduce_kernel_name(32, 8_000_000, "avgm") == "reduce_late_half_kernel"
+    assert _hops("f16").reduce_kernel_name(K, n, "adam") == "reduce_half_kernel"     # float16: never by default
+    monkeypatch.setenv("APPFL_AMD_HALF_LATE", "0")
+    assert o.reduce_kernel_name(K, n, "adam") == "reduce_half_kernel"
+    want = _late_rounds(o, dt, "adam", K, n, 0)
+    monkeypatch.setenv("APPFL_AMD_HALF_LATE", mode)
+    got = _late_rounds(o, dt, "adam", K, n, 0)
+    for a, b, what in zip(got, want, "gmv"):
+        assert torch.equal(a, b), (mode, what)
