@@ -417,7 +417,8 @@ constexpr int kLateVpt = FA_HALF_LATE_VPT;
 
 template <int OPT, int HALF>
 __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const ReduceHArgs a) {
-    static_assert(OPT != FA_OPT_NONE, "plain FedAvg has no epilogue to defer");
+    // (plain FedAvg has no epilogue to defer: its NEW g is what gets parked, and a phase ends with
+    // the burst of those alone)
     constexpr int VPT = kLateVpt, U = FA_HALF_LATE_AHEAD, P = kLateTiles, VEC = kWide;
     constexpr bool kHasM = OPT >= FA_OPT_ADAM;
     __shared__ u4 stash[P][VPT][kThreads];
@@ -545,10 +546,38 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const Red
             t.w = narrow2<HALF>(s[p].e[6], s[p].e[7]);
             stash[j][p][threadIdx.x] = t;       // every thread only touches its own slots: no barrier
         }
+        if constexpr (OPT == FA_OPT_NONE) {
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) {
+                u4 t;
+                float r[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r[e] = rnd<HALF>(g[p].e[e] + s[p].e[e]);
+                t.x = narrow2<HALF>(r[0], r[1]);
+                t.y = narrow2<HALF>(r[2], r[3]);
+                t.z = narrow2<HALF>(r[4], r[5]);
+                t.w = narrow2<HALF>(r[6], r[7]);
+                stash[j][p][threadIdx.x] = t;
+            }
+        }
         if (j == P - 1 || ct + 1 == ntiles) {
             const unsigned first = ct - static_cast<unsigned>(j);
             const int j_lo = (ct < static_cast<unsigned>(P) && static_cast<unsigned>(j) >= ct) ? j - static_cast<int>(ct) : 0;
             if (phased) grid_meet(meet);
+            if constexpr (OPT == FA_OPT_NONE) {
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.g, 0, -1, 0x00020000);
+#pragma unroll 1
+                for (int jj = j_lo; jj <= j; ++jj) {
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        bool live;
+                        const unsigned i = index(first + jj, p, live);
+                        if (live) __builtin_amdgcn_raw_buffer_store_b128(stash[jj][p][threadIdx.x], rs, i * 16u, 0, 17);
+                    }
+                }
+                if (phased) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                goto next_tile;
+            }
             // the epilogue over the parked tiles: all of a tile's g / m / v loads are issued at
             // once, the next tile's fly while this tile's formulas are evaluated and stored
             Raw<VEC> gq[2][VPT], mq[2][VPT], vq[2][VPT];
@@ -600,6 +629,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const Red
             }
             if (phased) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the burst before the next phase's loads
         }
+    next_tile:
 #pragma unroll
         for (int p = 0; p < VPT; ++p) idx[p] = idn[p];
     }
@@ -837,6 +867,10 @@ int late_mode() {
 // behind -- 11.7-47 M elements x 8-100 clients +4...+42 % kernel time.
 bool late_wins(int half, int opt, int K, double tiles) {
     if (half != FA_HALF_BF16) return false;
+    // plain FedAvg (the new g parked, one result stream): 8 M elements x 24 / 32 / 64 / 100 clients
+    // -2.4 / -3.6 / -8.2 / -8.1 %, 11.7 M x 100 -10.4 % (0.750 -> 0.837 of peak), 25.6 M x 24 / 64 -2.4 /
+    // -7.9 %, 162.5 M x 16 / 32 -2.3 / -6.3 %; behind at 16 clients elsewhere (+0.5...+5 %) and below
+    if (opt == FA_OPT_NONE) return (K >= 24 && tiles >= 3.5) || (K >= 16 && tiles >= 70.0);
     if (opt == FA_OPT_AVGM) return (K >= 32 && tiles >= 3.5) || (K >= 24 && tiles >= 12.0) || (K >= 16 && tiles >= 40.0);
     return (K >= 48 && tiles >= 3.5) || (K >= 32 && tiles >= 12.0) || (K >= 24 && tiles >= 22.0);
 }
@@ -846,7 +880,7 @@ bool late_wins(int half, int opt, int K, double tiles) {
 template <int HALF>
 bool launch_late_half(int opt, const ReduceHArgs& a0, hipStream_t st) {
     const int mode = late_mode();
-    if (!mode || opt == FA_OPT_NONE || !a0.last || !a0.apply || a0.step_in || a0.step_out) return false;
+    if (!mode || !a0.last || !a0.apply || a0.step_in || a0.step_out) return false;
     const int G = fa_internal::cu_count();
     if (mode != 4 && !late_wins(HALF, opt, a0.K, static_cast<double>(a0.n) / (static_cast<double>(G) * kThreads * kLateVpt)))
         return false;
@@ -855,6 +889,7 @@ bool launch_late_half(int opt, const ReduceHArgs& a0, hipStream_t st) {
     a.sync_groups = mode == 3 ? 1 : 2;
     const dim3 grid(G), block(kThreads);
     switch (opt) {
+        case FA_OPT_NONE: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_NONE, HALF>), grid, block, 0, st, a); break;
         case FA_OPT_AVGM: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_AVGM, HALF>), grid, block, 0, st, a); break;
         case FA_OPT_ADAM: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_ADAM, HALF>), grid, block, 0, st, a); break;
         case FA_OPT_YOGI: hipLaunchKernelGGL((reduce_late_half_kernel<FA_OPT_YOGI, HALF>), grid, block, 0, st, a); break;
@@ -1009,7 +1044,7 @@ int opt_step_half(void* step, void* m, void* v, size_t n, int opt, const HyperH&
 extern "C" {
 
 const char* fa_half_reduce_kernel_name(int K, size_t n, int opt, int half) {
-    if (K <= 0 || K > FA_KCHUNK || opt == FA_OPT_NONE || !late_mode()) return "reduce_half_kernel";
+    if (K <= 0 || K > FA_KCHUNK || !late_mode()) return "reduce_half_kernel";
     const double tiles = static_cast<double>(n / kWide) / (static_cast<double>(fa_internal::cu_count()) * kThreads * kLateVpt);
     return (late_mode() == 4 || late_wins(half, opt, K, tiles)) ? "reduce_late_half_kernel" : "reduce_half_kernel";
 }

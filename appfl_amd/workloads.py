@@ -128,6 +128,8 @@ WORKLOADS: Dict[str, Dict] = {
     "resnet50_fedadam_k24": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 24},
     "resnet50_fedadam_k32": {"table": lambda: resnet(50), "cls": "FedAdamAggregator", "K": 32},
     # a bfloat16 model: rows and state stay 2 bytes per element, every operation is rounded to bfloat16
+    "resnet18_fedavg_k100_bf16": {"table": lambda: as_dtype(resnet(18), torch.bfloat16),
+                                  "cls": "FedAvgAggregator", "K": 100},
     "resnet50_fedadam_k64_bf16": {"table": lambda: as_dtype(resnet(50), torch.bfloat16),
                                   "cls": "FedAdamAggregator", "K": 64},
     "vitb16_fedasync_bf16": {"table": lambda: as_dtype(vit_b_16(), torch.bfloat16), "cls": "FedAsyncAggregator", "K": 1},

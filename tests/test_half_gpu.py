@@ -656,19 +656,21 @@ def _late_rounds(o, dt, opt, K, n, shift, rounds=2):
     buf = lambda: torch.zeros(n + 16, dtype=dt, device="cuda")[shift:shift + n]     # noqa: E731
     g = buf().copy_((torch.randn(n, device="cuda", generator=gen) * 0.05).to(dt))
     m, v = buf(), buf()
-    if opt not in ("avgm",):
+    if opt not in ("avgm", "none"):
         o.fill(v, 1e-6)
     xs = [buf().copy_((g.float() + torch.randn(n, device="cuda", generator=gen) * 0.02).to(dt)) for _ in range(K)]
     w = [(k + 1) / (K * (K + 1) / 2) for k in range(K)]
     for _ in range(rounds):
-        o.reduce_opt(xs, w, g, None if opt == "avgm" else m, v, opt, lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
+        o.reduce_opt(xs, w, g, None if opt in ("avgm", "none") else m, None if opt == "none" else v, opt,
+                     lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
     torch.cuda.synchronize()
     return [t.clone().view(torch.int16) for t in (g, m, v)]
 
 
 @pytest.mark.parametrize("kind", list(KINDS))
 @pytest.mark.parametrize("opt,K,n,shift", [("adam", 49, 3_000_011, 0), ("avgm", 33, 2_200_003, 8), ("yogi", 7, 700_001, 0),
-                                           ("adagrad", 128, 300_007, 0), ("adam", 3, 1_048_576, 0)])
+                                           ("adagrad", 128, 300_007, 0), ("adam", 3, 1_048_576, 0),
+                                           ("none", 37, 2_600_003, 0), ("none", 2, 40_009, 8)])
 def test_late_epilogue_kernel_gives_the_bits_of_the_tile_kernel(kind, opt, K, n, shift, monkeypatch):
     """The persistent kernel forced on shapes of every kind (client counts that leave a remainder
     of the double-buffered batches, ragged lengths, a tile count that leaves CUs idle, buffers on
@@ -694,7 +696,8 @@ def test_late_epilogue_kernel_in_phases_on_a_long_vector(mode, monkeypatch):
     monkeypatch.delenv("APPFL_AMD_HALF_LATE", raising=False)
     assert o.reduce_kernel_name(K, n, "adam") == "reduce_late_half_kernel"
     assert o.reduce_kernel_name(16, n, "adam") == "reduce_half_kernel"
-    assert o.reduce_kernel_name(K, n, "none") == "reduce_half_kernel"
+    assert o.reduce_kernel_name(K, n, "none") == "reduce_late_half_kernel"
+    assert o.reduce_kernel_name(12, n, "none") == "reduce_half_kernel"
     assert o.reduce_kernel_name(32, 8_000_000, "avgm") == "reduce_late_half_kernel"
     assert _hops("f16").reduce_kernel_name(K, n, "adam") == "reduce_half_kernel"     # float16: never by default
     monkeypatch.setenv("APPFL_AMD_HALF_LATE", "0")

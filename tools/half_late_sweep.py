@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from appfl_amd import half_ops  # noqa: E402
 
 HP = dict(lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
-STATE = {"avgm": 2, "adam": 3, "yogi": 3, "adagrad": 3}
+STATE = {"none": 1, "avgm": 2, "adam": 3, "yogi": 3, "adagrad": 3}
 
 
 def timed(fn, reps=8):
@@ -36,9 +36,9 @@ def main():
             g = torch.empty(n, dtype=dt, device="cuda").normal_(0, 0.05)
             m, v = torch.zeros_like(g), torch.full_like(g, 1e-3)
             xs, w = [rows[k] for k in range(K)], [1.0 / K] * K
-            for opt in ("adam", "avgm"):
+            for opt in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("adam", "avgm")):
                 def run():
-                    o.reduce_opt(xs, w, g, None if opt == "avgm" else m, v, opt, **HP)
+                    o.reduce_opt(xs, w, g, None if opt in ("avgm", "none") else m, None if opt == "none" else v, opt, **HP)
                 out = []
                 for mode in ("0", "4", "0", "4"):
                     os.environ["APPFL_AMD_HALF_LATE"] = mode
