@@ -89,6 +89,7 @@ SIGNATURES = {
     "fa_fill_f64": (_i, [_p, _d, _sz, _p]),
     "fa_half_round_scalar": (_f, [_d, _i]),
     "fa_half_reduce_kernel_name": (C.c_char_p, [_i, _sz, _i, _i]),
+    "fa_half_reduce_opt_ex": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _i, C.c_uint, _p]),
     "fa_half_reduce_opt": (_i, [_p, _p, _i, _p, _p, _p, _sz, _i, _d, _d, _d, _d, _p, _p, _i, _p]),
     "fa_half_reduce_step": (_i, [_p, _p, _i, _p, _p, _sz, _i, _p]),
     "fa_half_reduce_step_resume": (_i, [_p, _p, _i, _i, _p, _p, _sz, _i, _p]),

@@ -292,6 +292,7 @@ struct ReduceHArgs {
     unsigned* sync_word;   // late-epilogue kernel: the counter its blocks meet on (NULL: no meetings)
     unsigned sync_epoch;   // ... and this launch's tag in it
     int sync_groups;       // 2: the odd and the even XCDs' blocks meet apart, half a phase shifted; 1: all together
+    int no_persistent;     // host side only: keep this launch on the tile-per-block kernel (FA_ROUTE_NO_PERSISTENT)
 };
 
 // One block walks tiles of kThreads * VPT elements of width VEC; thread t owns elements
@@ -880,7 +881,7 @@ bool late_wins(int half, int opt, int K, double tiles) {
 template <int HALF>
 bool launch_late_half(int opt, const ReduceHArgs& a0, hipStream_t st) {
     const int mode = late_mode();
-    if (!mode || !a0.last || !a0.apply || a0.step_in || a0.step_out) return false;
+    if (!mode || a0.no_persistent || !a0.last || !a0.apply || a0.step_in || a0.step_out) return false;
     const int G = fa_internal::cu_count();
     if (mode != 4 && !late_wins(HALF, opt, a0.K, static_cast<double>(a0.n) / (static_cast<double>(G) * kThreads * kLateVpt)))
         return false;
@@ -926,8 +927,9 @@ void launch_reduce_half(int opt, const ReduceHArgs& a, hipStream_t st) {
 // step_ws) already; the loop over the clients is taken up from there (same order, same bits).
 int reduce_half(const void* const* x, const double* w, int K, void* g, const void* g_ro, void* m, void* v,
                 size_t n, int opt, const HyperH& h, void* step_out, void* step_ws, int apply, int half,
-                hipStream_t st, int k_done = 0) {
+                hipStream_t st, int k_done = 0, unsigned flags = 0) {
     if (!x || !w || K <= 0 || !known(half)) return FA_ERR_INVALID;
+    if (flags & ~static_cast<unsigned>(FA_ROUTE_NO_PERSISTENT)) return FA_ERR_INVALID;
     if (k_done < 0 || k_done >= K) return FA_ERR_INVALID;
     if (k_done > 0 && !step_out && !step_ws) return FA_ERR_WORKSPACE;
     if (apply ? !g : (!g_ro || !step_out)) return FA_ERR_INVALID;
@@ -955,7 +957,7 @@ int reduce_half(const void* const* x, const double* w, int K, void* g, const voi
             for (int k = 0; k < K; ++k) xs[static_cast<size_t>(k)] = at(x[k], off);
             int rc = reduce_half(xs.data(), w, K, at(g, off), at(g_ro, off), at(m, off), at(v, off),
                                  n - off < kSegmentH ? n - off : kSegmentH, opt, h, at(step_out, off),
-                                 at(step_ws, off), apply, half, st, k_done);
+                                 at(step_ws, off), apply, half, st, k_done, flags);
             if (rc != FA_OK) return rc;
         }
         return FA_OK;
@@ -973,6 +975,7 @@ int reduce_half(const void* const* x, const double* w, int K, void* g, const voi
         a.last = (ch == chunks - 1);
         a.apply = apply;
         a.h = h;
+        a.no_persistent = (flags & FA_ROUTE_NO_PERSISTENT) != 0;
         const int o = a.last ? opt : FA_OPT_NONE;
         for (int part = 0; part < 2; ++part) {
             const size_t lo = part ? body : 0, cnt = part ? n - body : body;
@@ -1058,6 +1061,13 @@ int fa_half_reduce_opt(const void* const* x, const double* w, int K, void* g, vo
                        void* step_ws, int half, fa_stream_t stream) {
     return reduce_half(x, w, K, g, nullptr, m, v, n, opt, make_hyper_h(lr, beta1, beta2, tau, half), step_out,
                        step_ws, 1, half, as_stream(stream));
+}
+
+int fa_half_reduce_opt_ex(const void* const* x, const double* w, int K, void* g, void* m, void* v, size_t n,
+                          int opt, double lr, double beta1, double beta2, double tau, void* step_out,
+                          void* step_ws, int half, unsigned flags, fa_stream_t stream) {
+    return reduce_half(x, w, K, g, nullptr, m, v, n, opt, make_hyper_h(lr, beta1, beta2, tau, half), step_out,
+                       step_ws, 1, half, as_stream(stream), 0, flags);
 }
 
 int fa_half_reduce_step(const void* const* x, const double* w, int K, const void* g, void* step_out, size_t n,

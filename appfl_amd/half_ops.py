@@ -45,8 +45,10 @@ class HalfOps:
                    opt: str = "none", lr: float = 0.0, beta1: float = 0.0, beta2: float = 0.0,
                    tau: float = 0.0, step_out=None, step_ws=None, n: Optional[int] = None,
                    persistent: bool = True) -> None:
+        """`persistent=False` (fa_half_reduce_opt_ex with FA_ROUTE_NO_PERSISTENT) keeps this call on
+        the tile-per-block kernel: for a round that runs beside other kernels on the same GPU."""
         if g.dtype != self.dtype:
-            return ops.reduce_opt(x, w, g, m, v, opt, lr, beta1, beta2, tau, step_out, step_ws, n)
+            return ops.reduce_opt(x, w, g, m, v, opt, lr, beta1, beta2, tau, step_out, step_ws, n, persistent)
         dt = self.dtype
         n = g.numel() if n is None else n
         if len(x) != len(w):
@@ -54,11 +56,12 @@ class HalfOps:
         for t in (m, v, step_out, step_ws):
             if t is not None and t.numel() < n:
                 raise ValueError("state / workspace tensor shorter than n")
-        rc = N.load().fa_half_reduce_opt(
+        rc = N.load().fa_half_reduce_opt_ex(
             _check_rows(x, n, dt), N.double_array([float(t) for t in w]), len(x), _dev(g, dt),
             _dev(m, dt), _dev(v, dt), n, OPT_CODES[opt], float(lr), float(beta1), float(beta2),
-            float(tau), _dev(step_out, dt), _dev(step_ws, dt), self.half, _stream(g))
-        N.check(rc, "fa_half_reduce_opt")
+            float(tau), _dev(step_out, dt), _dev(step_ws, dt), self.half,
+            N.FA_ROUTE_DEFAULT if persistent else N.FA_ROUTE_NO_PERSISTENT, _stream(g))
+        N.check(rc, "fa_half_reduce_opt_ex")
 
     def reduce_step(self, x, w, g, step_out, n: Optional[int] = None, k_done: int = 0) -> None:
         """Weighted step alone into `step_out`; `k_done` > 0: `step_out` holds the partial step of

@@ -430,6 +430,12 @@ const char* fa_half_reduce_kernel_name(int K, size_t n, int opt, int half);
 int fa_half_reduce_opt(const void* const* x, const double* w, int K, void* g, void* m, void* v,
                        size_t n, int opt, double lr, double beta1, double beta2, double tau,
                        void* step_out, void* step_ws, int half, fa_stream_t stream);
+/* fa_half_reduce_opt with the per-call routing word of fa_reduce_opt_ex: FA_ROUTE_NO_PERSISTENT keeps
+ * this call off the persistent kernel (for rounds that run beside other kernels on the same GPU);
+ * same results bit for bit; unknown flag bits return FA_ERR_INVALID.  No counterpart in the reference. */
+int fa_half_reduce_opt_ex(const void* const* x, const double* w, int K, void* g, void* m, void* v,
+                          size_t n, int opt, double lr, double beta1, double beta2, double tau,
+                          void* step_out, void* step_ws, int half, unsigned flags, fa_stream_t stream);
 int fa_half_reduce_step(const void* const* x, const double* w, int K, const void* g, void* step_out,
                         size_t n, int half, fa_stream_t stream);
 /* The client loop cut between two clients, as fa_reduce_step_resume / fa_round_resume cut it

@@ -625,6 +625,8 @@ def test_the_16_bit_entry_points_refuse_bad_arguments_with_their_error_codes():
     xm, wm = N.ptr_array([xs[0].data_ptr()] * many), N.double_array([1.0 / many] * many)
     assert reduce_opt(x_=xm, w_=wm, K_=many) == WORKSPACE
     assert reduce_opt(x_=xm, w_=wm, K_=many, ws=P(step)) == 0
+    assert lib.fa_half_reduce_opt_ex(x, w, K, P(g), P(m), P(v), n, 2, *adam, None, None, BF, 8, None) == INVALID   # unknown flag
+    assert lib.fa_half_reduce_opt_ex(x, w, K, P(g), P(m), P(v), n, 2, *adam, None, None, BF, 1, None) == 0
     torch.cuda.synchronize()
     g.copy_(before)
     # the other entry points
@@ -651,7 +653,7 @@ def test_the_16_bit_entry_points_refuse_bad_arguments_with_their_error_codes():
 
 # -- the persistent kernel with the late epilogue ------------------------------------------------------
 
-def _late_rounds(o, dt, opt, K, n, shift, rounds=2):
+def _late_rounds(o, dt, opt, K, n, shift, rounds=2, persistent=True):
     gen = torch.Generator(device="cuda").manual_seed(n + K)
     buf = lambda: torch.zeros(n + 16, dtype=dt, device="cuda")[shift:shift + n]     # noqa: E731
     g = buf().copy_((torch.randn(n, device="cuda", generator=gen) * 0.05).to(dt))
@@ -662,7 +664,7 @@ def _late_rounds(o, dt, opt, K, n, shift, rounds=2):
     w = [(k + 1) / (K * (K + 1) / 2) for k in range(K)]
     for _ in range(rounds):
         o.reduce_opt(xs, w, g, None if opt in ("avgm", "none") else m, None if opt == "none" else v, opt,
-                     lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3)
+                     lr=0.1, beta1=0.9, beta2=0.99, tau=1e-3, persistent=persistent)
     torch.cuda.synchronize()
     return [t.clone().view(torch.int16) for t in (g, m, v)]
 
@@ -707,3 +709,7 @@ def test_late_epilogue_kernel_in_phases_on_a_long_vector(mode, monkeypatch):
     got = _late_rounds(o, dt, "adam", K, n, 0)
     for a, b, what in zip(got, want, "gmv"):
         assert torch.equal(a, b), (mode, what)
+    # the per-call routing word keeps a round off it (the sharded rounds beside a gather)
+    kept_off = _late_rounds(o, dt, "adam", K, n, 0, persistent=False)
+    for a, b, what in zip(kept_off, want, "gmv"):
+        assert torch.equal(a, b), (mode, what, "kept off")
