@@ -856,7 +856,7 @@ int late_mode() {
 }
 
 // Where the late-epilogue kernel is ahead of the tile-per-block kernel (same process, kernel time,
-// bfloat16, tools/half_late_sweep.py, profiles/r03_half_late_sweep.log; `tiles` = tiles of 256 x 4 vectors per CU).  Two-moment
+// bfloat16, tools/half_late_sweep.py; `tiles` = tiles of 256 x 4 vectors per CU).  Two-moment
 // optimizers: 8 M elements (3.8 tiles) x 48 / 64 / 100 clients -3.7 / -5.5 / -9.6 %, 25.6 M (12 tiles)
 // x 32 / 48 / 64 / 100 -1.1 / -7.0 / -8.9 / -10.6 %, 47 M (22 tiles) x 24 / 32 / 64 -1.0 / -5.2 / -9.7 %,
 // 162.5 M x 24 / 32 -4.1 / -5.4 %; behind at fewer clients (25.6 M x 24 / 16 / 8 +4 / +17 / +42 %:
