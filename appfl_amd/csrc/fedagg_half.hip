@@ -11,8 +11,9 @@
 // evaluates the fp32 formula of the entry point of the same name with each operation's result
 // passed through rnd<HALF>() -- the hardware's round-to-nearest-even conversion to the 16-bit
 // type and back -- and narrows what it stores (exact again: every stored value came out of
-// rnd).  Results equal the reference's bit for bit.  Plain streaming kernels: 128-bit loads of
-// eight elements where the buffers allow it, eight client loads in flight.
+// rnd).  Results equal the reference's bit for bit.  Streaming kernels: 128-bit loads of eight
+// elements where the buffers allow it, eight client loads in flight; the rounds of long client
+// lists on bfloat16 run on a persistent kernel that writes its results in chip-wide bursts.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,8 +45,9 @@ constexpr size_t kSegmentH = size_t(1) << 30;   // elements one reduce launch co
 // compiled out 0.611 ms -- the roundings are not what bounds it.  With the loads in flight kept
 // packed (so that deeper batches fit in registers): 1 x 8 / 1 x 16 / 1 x 32 0.621, 2 x 4 0.622,
 // 2 x 8 0.625, 4 x 8 0.630, 2 x 16 0.634, 4 x 16 0.719: the shape is not what bounds it either;
-// this is where the fp32 tile-per-block kernel sits for the same round (0.70-0.72 of peak), whose
-// persistent, phase-writing successor has no 16-bit counterpart.
+// this is where the fp32 tile-per-block kernel sits for the same round (0.70-0.72 of peak); long
+// client lists on bfloat16 therefore take the persistent kernel further down
+// (reduce_late_half_kernel), which parks a phase's results on chip and writes them as one burst.
 #ifndef FA_HALF_VPT
 #define FA_HALF_VPT 1
 #endif
