@@ -418,6 +418,103 @@ constexpr int kLateTiles = FA_HALF_LATE_TILES;
 #endif
 constexpr int kLateVpt = FA_HALF_LATE_VPT;
 
+// g and the running averaged step of one 16-byte vector (eight elements) in the persistent
+// kernel.  bfloat16: widened to fp32, every operation rounded by rnd<>.  float16: kept packed, and
+// the two tensor-tensor operations of a client's term -- x - g and step + term -- run as native
+// packed float16 instructions: PyTorch evaluates them in fp32 and rounds to float16, and for + and
+// - of float16 values that double rounding equals the one correct rounding the instruction does
+// (fp32 carries 24 >= 2 * 11 + 2 significant bits; sums that fall into the subnormal range are
+// exact).  The product with the fp32 weight keeps its two roundings (fp32, then float16): two
+// instructions, with the product made opaque in between so that they are not merged into one
+// mixed-precision instruction that rounds once.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+// (by value: a bit cast straight from a vector's element reads the vector's first element)
+__device__ __forceinline__ h2 as_h2(unsigned u) { return __builtin_bit_cast(h2, u); }
+__device__ __forceinline__ unsigned as_bits(h2 v) { return __builtin_bit_cast(unsigned, v); }
+
+template <int HALF>
+struct LateAcc {
+    PackH<kWide> g, s;
+    __device__ __forceinline__ void start(const Raw<kWide>& gr) {
+        g = widen<HALF, kWide>(gr);
+#pragma unroll
+        for (int e = 0; e < kWide; ++e) s.e[e] = 0.0f;
+    }
+    __device__ __forceinline__ void fold(const Raw<kWide>& xr, float w) {
+        const PackH<kWide> x = widen<HALF, kWide>(xr);
+#pragma unroll
+        for (int e = 0; e < kWide; ++e) {
+            float d = rnd<HALF>(x.e[e] - g.e[e]);
+            float wd = rnd<HALF>(d * w);
+            s.e[e] = rnd<HALF>(s.e[e] + wd);
+        }
+    }
+    __device__ __forceinline__ u4 step() const {
+        u4 t;
+        t.x = narrow2<HALF>(s.e[0], s.e[1]);
+        t.y = narrow2<HALF>(s.e[2], s.e[3]);
+        t.z = narrow2<HALF>(s.e[4], s.e[5]);
+        t.w = narrow2<HALF>(s.e[6], s.e[7]);
+        return t;
+    }
+    __device__ __forceinline__ u4 applied() const {      // g + step
+        float r[kWide];
+#pragma unroll
+        for (int e = 0; e < kWide; ++e) r[e] = rnd<HALF>(g.e[e] + s.e[e]);
+        u4 t;
+        t.x = narrow2<HALF>(r[0], r[1]);
+        t.y = narrow2<HALF>(r[2], r[3]);
+        t.z = narrow2<HALF>(r[4], r[5]);
+        t.w = narrow2<HALF>(r[6], r[7]);
+        return t;
+    }
+};
+
+#ifndef FA_HALF_F16_NATIVE
+#define FA_HALF_F16_NATIVE 1
+#endif
+#if FA_HALF_F16_NATIVE
+template <>
+struct LateAcc<FA_HALF_F16> {
+    h2 g[4], s[4];
+    __device__ __forceinline__ void start(const Raw<kWide>& gr) {
+        g[0] = as_h2(gr.v.x);
+        g[1] = as_h2(gr.v.y);
+        g[2] = as_h2(gr.v.z);
+        g[3] = as_h2(gr.v.w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = h2{static_cast<_Float16>(0.0f), static_cast<_Float16>(0.0f)};
+    }
+    __device__ __forceinline__ void fold(const Raw<kWide>& xr, float w) {
+        const h2 x[4] = {as_h2(xr.v.x), as_h2(xr.v.y), as_h2(xr.v.z), as_h2(xr.v.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const h2 d = x[q] - g[q];
+            f2 pr = __builtin_convertvector(d, f2) * w;
+            __asm__("" : "+v"(pr));
+            s[q] = s[q] + __builtin_convertvector(pr, h2);
+        }
+    }
+    __device__ __forceinline__ u4 step() const {
+        u4 t;
+        t.x = as_bits(s[0]);
+        t.y = as_bits(s[1]);
+        t.z = as_bits(s[2]);
+        t.w = as_bits(s[3]);
+        return t;
+    }
+    __device__ __forceinline__ u4 applied() const {
+        u4 t;
+        t.x = as_bits(g[0] + s[0]);
+        t.y = as_bits(g[1] + s[1]);
+        t.z = as_bits(g[2] + s[2]);
+        t.w = as_bits(g[3] + s[3]);
+        return t;
+    }
+};
+#endif
+
 template <int OPT, int HALF>
 __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const ReduceHArgs a) {
     // (plain FedAvg has no epilogue to defer: its NEW g is what gets parked, and a phase ends with
@@ -482,27 +579,15 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const Red
     }
     if (nb > 0) request(0, xa, idx);
     for (unsigned ct = 0; ct < ntiles; ++ct) {
-        PackH<VEC> g[VPT], s[VPT];
+        LateAcc<HALF> acc[VPT];
 #pragma unroll
-        for (int p = 0; p < VPT; ++p) {
-            g[p] = widen<HALF, VEC>(gr[p]);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) s[p].e[e] = 0.0f;
-        }
+        for (int p = 0; p < VPT; ++p) acc[p].start(gr[p]);
         auto fold = [&](int k0, const Raw<VEC> (&buf)[U][VPT]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float w = a.w[k0 + u];
 #pragma unroll
-                for (int p = 0; p < VPT; ++p) {
-                    const PackH<VEC> x = widen<HALF, VEC>(buf[u][p]);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) {
-                        float d = rnd<HALF>(x.e[e] - g[p].e[e]);
-                        float wd = rnd<HALF>(d * w);
-                        s[p].e[e] = rnd<HALF>(s[p].e[e] + wd);
-                    }
-                }
+                for (int p = 0; p < VPT; ++p) acc[p].fold(buf[u][p], w);
             }
         };
         int b = 0;
@@ -520,15 +605,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const Red
 #pragma unroll
             for (int p = 0; p < VPT; ++p) xr[p] = load_raw<VEC, true>(a.x[k], idx[p]);
 #pragma unroll
-            for (int p = 0; p < VPT; ++p) {
-                const PackH<VEC> x = widen<HALF, VEC>(xr[p]);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    float d = rnd<HALF>(x.e[e] - g[p].e[e]);
-                    float wd = rnd<HALF>(d * w);
-                    s[p].e[e] = rnd<HALF>(s[p].e[e] + wd);
-                }
-            }
+            for (int p = 0; p < VPT; ++p) acc[p].fold(xr[p], w);
         }
         if (ct + 1 < ntiles) {
 #pragma unroll
@@ -541,28 +618,8 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const Red
         }
         const int j = static_cast<int>((ct + shift) % P);
 #pragma unroll
-        for (int p = 0; p < VPT; ++p) {
-            u4 t;
-            t.x = narrow2<HALF>(s[p].e[0], s[p].e[1]);
-            t.y = narrow2<HALF>(s[p].e[2], s[p].e[3]);
-            t.z = narrow2<HALF>(s[p].e[4], s[p].e[5]);
-            t.w = narrow2<HALF>(s[p].e[6], s[p].e[7]);
-            stash[j][p][threadIdx.x] = t;       // every thread only touches its own slots: no barrier
-        }
-        if constexpr (OPT == FA_OPT_NONE) {
-#pragma unroll
-            for (int p = 0; p < VPT; ++p) {
-                u4 t;
-                float r[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) r[e] = rnd<HALF>(g[p].e[e] + s[p].e[e]);
-                t.x = narrow2<HALF>(r[0], r[1]);
-                t.y = narrow2<HALF>(r[2], r[3]);
-                t.z = narrow2<HALF>(r[4], r[5]);
-                t.w = narrow2<HALF>(r[6], r[7]);
-                stash[j][p][threadIdx.x] = t;
-            }
-        }
+        for (int p = 0; p < VPT; ++p)      // every thread only touches its own slots: no barrier
+            stash[j][p][threadIdx.x] = OPT == FA_OPT_NONE ? acc[p].applied() : acc[p].step();
         if (j == P - 1 || ct + 1 == ntiles) {
             const unsigned first = ct - static_cast<unsigned>(j);
             const int j_lo = (ct < static_cast<unsigned>(P) && static_cast<unsigned>(j) >= ct) ? j - static_cast<int>(ct) : 0;
@@ -865,11 +922,17 @@ int late_mode() {
 // at one wave per SIMD a short client list leaves the epilogue nothing to hide behind) and on
 // short vectors (4.5 M x 48 +8 %).  FedAvgM (two result streams): from 32 clients at 3.5 tiles
 // (8 M x 32 / 64 -2.3 / -9.1 %), 24 at 12 (25.6 M -1.3 %), 16 at 40 (87 M -3.6 %).
-// float16 stays on the tile-per-block kernel at every shape: its roundings are two conversions
-// each (bfloat16: one instruction), and at one wave per SIMD that arithmetic has nothing to hide
-// behind -- 11.7-47 M elements x 8-100 clients +4...+42 % kernel time.
+// float16 (x - g and step + term as native packed instructions, see LateAcc; with every
+// operation rounded through fp32 the kernel was 4-42 % BEHIND at every shape): later break-even
+// than bfloat16, its tile-per-block kernel being a little faster -- two-moment optimizers 25.6 M x
+// 48 / 64 / 100 -4.2 / -4.1 / -7.4 %, 47 M x 64 -8.5 %, 8-17 M x 64 -0.8...-4.2 %, but 17 M x 48 +4 %;
+// FedAvgM 25.6 M x 48 / 64 -3.3 / -5.3 %, 47 M x 32 -3.8 %; plain FedAvg 8-87 M x 48-64 -3.4...-5.9 %.
 bool late_wins(int half, int opt, int K, double tiles) {
-    if (half != FA_HALF_BF16) return false;
+    if (half != FA_HALF_BF16) {
+        if (opt == FA_OPT_NONE) return (K >= 48 && tiles >= 3.5) || (K >= 32 && tiles >= 22.0);
+        if (opt == FA_OPT_AVGM) return (K >= 64 && tiles >= 3.5) || (K >= 48 && tiles >= 8.0) || (K >= 32 && tiles >= 22.0);
+        return (K >= 64 && tiles >= 3.5) || (K >= 48 && tiles >= 12.0);
+    }
     // plain FedAvg (the new g parked, one result stream): 8 M elements x 24 / 32 / 64 / 100 clients
     // -2.4 / -3.6 / -8.2 / -8.1 %, 11.7 M x 100 -10.4 % (0.750 -> 0.837 of peak), 25.6 M x 24 / 64 -2.4 /
     // -7.9 %, 162.5 M x 16 / 32 -2.3 / -6.3 %; behind at 16 clients elsewhere (+0.5...+5 %) and below

@@ -424,7 +424,7 @@ float fa_half_round_scalar(double x, int half);
  * elements and optimizer `opt` on the current device (fa_reduce_kernel_name for the 16-bit entry
  * points): "reduce_half_kernel", one tile per block, or "reduce_late_half_kernel", the persistent
  * kernel that parks a phase's averaged steps on chip and runs the optimizer epilogue of the phase
- * as one burst (long client lists of the optimizer rounds on bfloat16; the environment variable
+ * as one burst (long client lists; the environment variable
  * APPFL_AMD_HALF_LATE=0, a benchmark knob read at every launch, keeps every round off it). */
 const char* fa_half_reduce_kernel_name(int K, size_t n, int opt, int half);
 int fa_half_reduce_opt(const void* const* x, const double* w, int K, void* g, void* m, void* v,

@@ -701,7 +701,8 @@ def test_late_epilogue_kernel_in_phases_on_a_long_vector(mode, monkeypatch):
     assert o.reduce_kernel_name(K, n, "none") == "reduce_late_half_kernel"
     assert o.reduce_kernel_name(12, n, "none") == "reduce_half_kernel"
     assert o.reduce_kernel_name(32, 8_000_000, "avgm") == "reduce_late_half_kernel"
-    assert _hops("f16").reduce_kernel_name(K, n, "adam") == "reduce_half_kernel"     # float16: never by default
+    assert _hops("f16").reduce_kernel_name(K, n, "adam") == "reduce_late_half_kernel"
+    assert _hops("f16").reduce_kernel_name(32, n, "adam") == "reduce_half_kernel"    # float16 breaks even later
     monkeypatch.setenv("APPFL_AMD_HALF_LATE", "0")
     assert o.reduce_kernel_name(K, n, "adam") == "reduce_half_kernel"
     want = _late_rounds(o, dt, "adam", K, n, 0)
@@ -709,6 +710,17 @@ def test_late_epilogue_kernel_in_phases_on_a_long_vector(mode, monkeypatch):
     got = _late_rounds(o, dt, "adam", K, n, 0)
     for a, b, what in zip(got, want, "gmv"):
         assert torch.equal(a, b), (mode, what)
+    if mode == "1":      # float16, whose client terms run as native packed instructions there
+        o16 = _hops("f16")
+        for opt in ("yogi", "none"):
+            monkeypatch.setenv("APPFL_AMD_HALF_LATE", "0")
+            want16 = _late_rounds(o16, torch.float16, opt, 64, n, 0)
+            monkeypatch.setenv("APPFL_AMD_HALF_LATE", "1")
+            assert o16.reduce_kernel_name(64, n, opt) == "reduce_late_half_kernel"
+            got16 = _late_rounds(o16, torch.float16, opt, 64, n, 0)
+            for a, b, what in zip(got16, want16, "gmv"):
+                assert torch.equal(a, b), ("f16", opt, what)
+        monkeypatch.setenv("APPFL_AMD_HALF_LATE", mode)
     # the per-call routing word keeps a round off it (the sharded rounds beside a gather)
     kept_off = _late_rounds(o, dt, "adam", K, n, 0, persistent=False)
     for a, b, what in zip(kept_off, want, "gmv"):
