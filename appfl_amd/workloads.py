@@ -132,6 +132,8 @@ WORKLOADS: Dict[str, Dict] = {
                                   "cls": "FedAvgAggregator", "K": 100},
     "resnet50_fedadam_k64_bf16": {"table": lambda: as_dtype(resnet(50), torch.bfloat16),
                                   "cls": "FedAdamAggregator", "K": 64},
+    "resnet50_fedadam_k64_f16": {"table": lambda: as_dtype(resnet(50), torch.float16),
+                                 "cls": "FedAdamAggregator", "K": 64},
     "vitb16_fedasync_bf16": {"table": lambda: as_dtype(vit_b_16(), torch.bfloat16), "cls": "FedAsyncAggregator", "K": 1},
     "vitb16_fedbuff_flush_bf16": {"table": lambda: as_dtype(vit_b_16(), torch.bfloat16), "cls": "FedBuffAggregator",
                                   "K": 16, "kind": "flush"},

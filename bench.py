@@ -47,7 +47,8 @@ SHARDED_WORKLOAD = "flat1300m_fedavg_k32"
 NORTH_STAR_WORKLOAD = "resnet50_fedadam_k64"
 SHARDED_EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64"]
 EXTRA_WORKLOADS = ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "resnet50_fedavgm_k64",
-                   "resnet18_fedavg_k100_bf16", "resnet50_fedadam_k64_bf16", "vitb16_fedasync_bf16",
+                   "resnet18_fedavg_k100_bf16", "resnet50_fedadam_k64_bf16", "resnet50_fedadam_k64_f16",
+                   "vitb16_fedasync_bf16",
                    "vitb16_fedcompass_group_k8_bf16", "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
                    "vitb16_fedbuff_first", "vitb16_fedbuff_middle", "vitb16_fedbuff_flush",
                    "vitb16_fedcompass_group_k8", "vitb16_fedqueue_replace_k16"]

@@ -61,7 +61,8 @@ def test_one_gpu_line_lists_every_benchmark_configuration():
     assert out["config"]["workload"] == "resnet18_fedavg_k100" and out["scaling"] == "weak"
     names = [w["workload"] for w in out["workloads"]]
     assert names == ["resnet50_fedadam_k64", "resnet50_fedyogi_k64", "resnet50_fedavgm_k64",
-                     "resnet18_fedavg_k100_bf16", "resnet50_fedadam_k64_bf16", "vitb16_fedasync_bf16",
+                     "resnet18_fedavg_k100_bf16", "resnet50_fedadam_k64_bf16", "resnet50_fedadam_k64_f16",
+                     "vitb16_fedasync_bf16",
                      "vitb16_fedcompass_group_k8_bf16", "flat162m_fedavg_k32", "vitb16_fedasync", "vitb16_fedbuff_k16",
                      "vitb16_fedbuff_first", "vitb16_fedbuff_middle", "vitb16_fedbuff_flush",
                      "vitb16_fedcompass_group_k8", "vitb16_fedqueue_replace_k16"]
@@ -79,6 +80,7 @@ def test_one_gpu_line_lists_every_benchmark_configuration():
         by_name["resnet50_fedadam_k64"]["algorithmic_bytes_per_launch"]
     assert by_name["resnet50_fedadam_k64_bf16"]["kernel"] == "reduce_late_half_kernel<adam,bfloat16>"
     assert by_name["resnet18_fedavg_k100_bf16"]["kernel"] == "reduce_late_half_kernel<none,bfloat16>"
+    assert by_name["resnet50_fedadam_k64_f16"]["kernel"] == "reduce_late_half_kernel<adam,float16>"
     assert out["north_star_target"]["workload"] == "resnet50_fedadam_k64"
     assert out["north_star_target"]["frac"] == out["workloads"][0]["frac"]
     # cold-state figures (state vectors rotated over independent sets) beside the warm ones
