@@ -471,6 +471,57 @@ struct LateAcc {
     }
 };
 
+#ifndef FA_HALF_BF16_PACKED
+#define FA_HALF_BF16_PACKED 1
+#endif
+#if FA_HALF_BF16_PACKED
+// bfloat16: the same operations on PAIRS of elements, so that the three fp32 operations of a
+// client's term are packed instructions (v_pk_add_f32 / v_pk_mul_f32: two elements each); every
+// result is still rounded on its own (one conversion per element).
+template <>
+struct LateAcc<FA_HALF_BF16> {
+    f2 g[4], s[4];
+    static __device__ __forceinline__ f2 wide(unsigned u) {
+        return f2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xFFFF0000u)};
+    }
+    static __device__ __forceinline__ f2 rnd2(f2 v) { return f2{rnd<FA_HALF_BF16>(v.x), rnd<FA_HALF_BF16>(v.y)}; }
+    static __device__ __forceinline__ unsigned bits(f2 v) { return narrow2<FA_HALF_BF16>(v.x, v.y); }
+    __device__ __forceinline__ void start(const Raw<kWide>& gr) {
+        g[0] = wide(gr.v.x);
+        g[1] = wide(gr.v.y);
+        g[2] = wide(gr.v.z);
+        g[3] = wide(gr.v.w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = f2{0.0f, 0.0f};
+    }
+    __device__ __forceinline__ void fold(const Raw<kWide>& xr, float w) {
+        const f2 x[4] = {wide(xr.v.x), wide(xr.v.y), wide(xr.v.z), wide(xr.v.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f2 d = rnd2(x[q] - g[q]);
+            const f2 wd = rnd2(d * w);
+            s[q] = rnd2(s[q] + wd);
+        }
+    }
+    __device__ __forceinline__ u4 step() const {
+        u4 t;
+        t.x = bits(s[0]);
+        t.y = bits(s[1]);
+        t.z = bits(s[2]);
+        t.w = bits(s[3]);
+        return t;
+    }
+    __device__ __forceinline__ u4 applied() const {
+        u4 t;
+        t.x = bits(rnd2(g[0] + s[0]));
+        t.y = bits(rnd2(g[1] + s[1]));
+        t.z = bits(rnd2(g[2] + s[2]));
+        t.w = bits(rnd2(g[3] + s[3]));
+        return t;
+    }
+};
+#endif
+
 #ifndef FA_HALF_F16_NATIVE
 #define FA_HALF_F16_NATIVE 1
 #endif
