@@ -889,6 +889,9 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
 #ifndef FA_LATE_BATCH
 #define FA_LATE_BATCH 3
 #endif
+#ifndef FA_LATE_FOLD_AHEAD
+#define FA_LATE_FOLD_AHEAD 2    /* clients ahead per vector while a tile is folded (A/B knob) */
+#endif
 #ifndef FA_LATE_DEBUG
 #define FA_LATE_DEBUG 0   /* 1-3: timing experiments that drop parts of the epilogue (wrong results) */
 #endif
@@ -956,7 +959,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceAr
             idx[p] = tile_index(ct, p, live);
         }
         TileRegs<4, VPT> r;
-        fold_tile<FA_OPT_NONE, 4, VPT, 16, true, true>(a, idx, r);
+        fold_tile<FA_OPT_NONE, 4, VPT, FA_LATE_FOLD_AHEAD, true, true>(a, idx, r);
         const int j = static_cast<int>((ct + shift) % P);
 #pragma unroll
         for (int p = 0; p < VPT; ++p) stash[j][p][threadIdx.x] = as_f4(r.s[p]);
@@ -1525,19 +1528,25 @@ int launch_late(const ReduceArgs& a0, hipStream_t st) {
 }
 
 // Whether a launch takes the persistent kernel with the late epilogue: the final form (weighted
-// step, epilogue, apply; no step output) of the TWO-MOMENT optimizers at mid-size client lists,
-// where neither the tile-per-block kernel hides the three result streams nor the software-pipelined
-// persistent kernel's two-tile phases pay yet (stash_wins below has priority).  Measured against
-// the tile-per-block kernel, same process (kernel time): 25.6 M elements x 24 / 28 / 32 / 36 clients
-// -1.2...-1.9 / -3.3 / -4.2...-4.9 / -3.5 %, 18 M x 32 -4.2 %, 35 M x 20 / 24 / 28 -3.7 / -3.6 / -3.0 %,
-// 47 M x 20 -2.1 %, 60 M x 16 / 20 -1.5 / -3.1 %; level or behind at 11.7 M elements (+-1 %, +3 % at
-// 24 clients), at 25.6 M x 16-20 (+1.4...+3 %) and wherever the pipelined persistent kernel is the
-// default (35 M x 32 +1 %, 87-162 M x 32 +3...+6 %, 25.6 M x 48-64 +-1 %); FedAvgM loses 7 % (its
-// wide tile-per-block shape is at 0.78 already).  fa_tune: stash == -3 forces it at every length
-// and client count, stash <= 0 otherwise keeps it off.
+// step, epilogue, apply; no step output) of an optimizer round.  Its tile fold keeps only TWO
+// clients x 4 vectors in flight per lane (FA_LATE_FOLD_AHEAD): at one wave per SIMD fewer live
+// registers beat deeper batches -- ResNet-50 size, FedAdam, kernel time against 16 clients ahead:
+// 24 / 32 / 64 clients -2.4 / -2.8 / -3.2 % (4 ahead: -2.4 / -2.7 / -1.6 %).  With that it is ahead of
+// the tile-per-block kernel AND of the software-pipelined persistent kernel over most of the
+// plane (same process, kernel time against the earlier default routing).  Two-moment optimizers:
+// 4.5 M elements x 32 / 48 / 100 clients -1.1 / -5.0 / -7.6 %, 8 M x 24 / 32 / 64 -1.5 / -3.1 / -7.4 %,
+// 11.7 M x 32 / 64 / 100 -5.9 / -6.0 / -6.7 %, 25.6 M x 20 / 40 / 64 / 100 -3.7 / -6.2 / -7.4 / -8.0 %,
+// 47 M x 16 / 24 / 64 -3.3 / -3.5 / -2.3 % (40-48 clients level), 87 M x 24-64 -5.6...-7.4 %, 162.5 M x
+// 24-32 -2.6...-2.9 %; behind at fewer clients (11.7-17 M x 16 +5...+6 %, x 20 +2 %).  FedAvgM: from
+// 48 clients everywhere (-3.0...-8.4 %) and from 32 on vectors of >= 40 tiles per CU (47 M x 32 / 40
+// -3.6 / -5.4 %, 87 M x 40 -4.7 %); below that its wide tile-per-block shape is ahead (8-25 M x
+// 16-32 +1...+7 %).  fa_tune: stash == -3 forces it at every length and client count, stash <= 0
+// otherwise keeps it off.
 bool late_wins(int opt, int K, uint64_t tiles_per_cu) {
+    if (opt == FA_OPT_AVGM) return (K >= 48 && tiles_per_cu >= 4) || (K >= 32 && tiles_per_cu >= 40);
     if (opt < FA_OPT_ADAM) return false;
-    return (K >= 24 && tiles_per_cu >= 16) || (K >= 20 && tiles_per_cu >= 32) || (K >= 16 && tiles_per_cu >= 56);
+    return (K >= 32 && tiles_per_cu >= 4) || (K >= 24 && tiles_per_cu >= 7) || (K >= 20 && tiles_per_cu >= 24) ||
+           (K >= 16 && tiles_per_cu >= 40);
 }
 bool stash_wins(int opt, int K, uint64_t tiles_per_cu);
 bool takes_late_path(int opt, int K, uint64_t nvec) {
@@ -1546,9 +1555,7 @@ bool takes_late_path(int opt, int K, uint64_t nvec) {
     if (g_shape.stash == -3) return true;
     if (g_shape.stash <= 0) return false;
     const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
-    const uint64_t tiles_per_cu = nvec / per_cu;
-    if (nvec >= per_cu * static_cast<uint64_t>(g_shape.stash) && stash_wins(opt, K, tiles_per_cu)) return false;
-    return late_wins(opt, K, tiles_per_cu);
+    return late_wins(opt, K, nvec / per_cu);      // (ahead of the software-pipelined persistent kernel too)
 }
 
 // Whether a launch takes the wide-batch persistent kernel: plain FedAvg, final form, from 6

@@ -313,7 +313,7 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
     if n > 1000000:
         assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
         assert ops.reduce_kernel_name(33, n, "none") == "reduce_kernel"
-        assert ops.reduce_kernel_name(K, n, "adam") == "reduce_kernel"
+        assert ops.reduce_kernel_name(K, n, "adam") == "reduce_late_kernel"
     code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI,
             "adagrad": O.OPT_ADAGRAD}[opt]
     base, xs = make_clients(n, K)
@@ -396,8 +396,8 @@ def test_wide_persistent_kernel_matches_oracle(n, K, nt):
     if n > 10_000_000 and K > 17:
         pytest.skip("host memory")
     assert ops.reduce_kernel_name(32, 162_500_000, "none") == "reduce_park_kernel"
-    assert ops.reduce_kernel_name(32, 162_500_000, "avgm") == "reduce_kernel"
-    assert ops.reduce_kernel_name(32, 162_500_000, "adam") == "reduce_stash_kernel"
+    assert ops.reduce_kernel_name(32, 162_500_000, "avgm") == "reduce_late_kernel"
+    assert ops.reduce_kernel_name(32, 162_500_000, "adam") == "reduce_late_kernel"
     assert ops.reduce_kernel_name(6, 162_500_000, "none") == "reduce_park_kernel"
     assert ops.reduce_kernel_name(5, 162_500_000, "none") == "reduce_kernel"
     assert ops.reduce_kernel_name(32, 65_000_000, "none") == "reduce_kernel"
@@ -868,17 +868,20 @@ def test_late_epilogue_persistent_kernel_matches_oracle(opt, hp, n, K, nt):
 
 
 def test_late_epilogue_kernel_where_the_library_routes_to_it():
-    """Mid-size client lists of the two-moment optimizers on vectors of >= 16 tiles per CU take
-    the late-epilogue kernel by default (several phases per group, a scalar tail after the 128-bit
-    body); shorter client lists, shorter vectors, FedAvgM and the shapes of the pipelined
-    persistent kernel do not.  The oracle's bits, moments included, three rounds."""
+    """Optimizer rounds take the late-epilogue kernel by default from 32 clients on vectors of
+    >= 4 tiles per CU, from fewer clients on longer vectors, and FedAvgM from 48 clients (several
+    phases per group, a scalar tail after the 128-bit body); shorter client lists, shorter
+    vectors and plain FedAvg do not.  The oracle's bits, moments included, three rounds."""
     from appfl_amd import ops
     name = ops.reduce_kernel_name
     assert name(32, 25_557_032, "adam") == name(24, 18_000_000, "yogi") == "reduce_late_kernel"
     assert name(20, 35_000_000, "adagrad") == name(16, 60_000_000, "adam") == "reduce_late_kernel"
-    assert name(20, 25_557_032, "adam") == name(32, 11_689_512, "adam") == "reduce_kernel"
-    assert name(32, 25_557_032, "avgm") == "reduce_kernel" and name(32, 25_557_032, "none") == "reduce_kernel"
-    assert name(64, 25_557_032, "adam") == name(32, 35_000_000, "adam") == "reduce_stash_kernel"
+    assert name(64, 25_557_032, "adam") == name(32, 11_689_512, "adam") == "reduce_late_kernel"
+    assert name(64, 25_557_032, "avgm") == name(32, 47_000_000, "avgm") == "reduce_late_kernel"
+    assert name(16, 25_557_032, "adam") == name(20, 11_689_512, "adam") == "reduce_kernel"
+    assert name(32, 3_000_000, "adam") == name(32, 25_557_032, "avgm") == "reduce_kernel"
+    assert name(32, 25_557_032, "none") == "reduce_kernel"
+    assert name(64, 25_557_032, "none") == name(64, 3_000_000, "avgm") == "reduce_stash_kernel"
     n, K = 17_000_003, 24
     base, xs = make_clients(n, K, spike=False)
     w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
