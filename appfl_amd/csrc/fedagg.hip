@@ -432,6 +432,9 @@ __global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
 // contiguous, is not.  A vector that the chip can park whole (up to 18 tiles per CU under plain
 // FedAvg) is written in one burst when all its reads are done (+1-2 % over several bursts).
 
+#ifndef FA_PARK_FOLD_AHEAD
+#define FA_PARK_FOLD_AHEAD 2    /* clients ahead per vector in the wide-batch persistent kernel (A/B knob) */
+#endif
 constexpr int kStashVpt = 4;
 constexpr int kStashUnroll = 8;
 constexpr unsigned kStashTile = kThreads * kStashVpt;                 // vectors per tile
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
             idx[p] = (off < tlen && i < r1) ? i : r1 - 1;   // idle lanes redo the last vector, never store
         }
         TileRegs<4, VPT> r;
-        fold_tile<OPT, 4, VPT, 16, true>(a, idx, r);
+        fold_tile<OPT, 4, VPT, FA_PARK_FOLD_AHEAD, true>(a, idx, r);
         const int j = static_cast<int>((ct + shift) % P);
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
@@ -1558,21 +1561,35 @@ bool takes_late_path(int opt, int K, uint64_t nvec) {
     return late_wins(opt, K, nvec / per_cu);      // (ahead of the software-pipelined persistent kernel too)
 }
 
-// Whether a launch takes the wide-batch persistent kernel: plain FedAvg, final form, from 6
-// clients on vectors of at least kParkMinTilesPerCu tiles per CU (fa_tune: stash == -2 forces it
-// at every length and client count, stash == 0 / -1 keep it off).  Against the tile-per-block
-// kernel on 162.5 M elements (fraction of peak): 2 / 4 clients 0.78 / 0.75 vs 0.73 / 0.74 (behind),
-// 5 / 6 / 7 / 8 / 12 / 14 clients 0.755 / 0.73 / 0.73 / 0.72 / 0.75 / 0.74 -> 0.76 / 0.755 / 0.76 /
-// 0.77 / 0.80 / 0.80; the same at 87 M, 120 M and 325 M elements; +2 % at 75 M.
+// Whether a launch takes the wide-batch persistent kernel: plain FedAvg, final form (fa_tune:
+// stash == -2 forces it at every length and client count, stash == 0 / -1 keep it off).  Its tile
+// fold keeps only TWO clients x 4 vectors in flight per lane (FA_PARK_FOLD_AHEAD; at one wave per
+// SIMD fewer live registers beat deeper batches: against 16 ahead 87 M elements x 32 clients -7 %,
+// 162.5 M x 12 -2.5 %, 25.6 M x 64 -7.5 %, 11.7 M x 100 -3.6 %).  Same process, kernel time:
+//  * from 6 clients on vectors of >= 72 tiles per CU, against the tile-per-block kernel (162.5 M
+//    elements, 16 ahead, fraction of peak): 2 / 4 clients 0.78 / 0.75 vs 0.73 / 0.74 (behind), 5 / 6 /
+//    7 / 8 / 12 / 14 clients 0.755 / 0.73 / 0.73 / 0.72 / 0.75 / 0.74 -> 0.76 / 0.755 / 0.76 / 0.77 /
+//    0.80 / 0.80; the same at 87 M, 120 M and 325 M elements; +2 % at 75 M;
+//  * from 40 clients on every vector of at least a tile per CU, against the pipelined persistent
+//    kernel (>= 48 clients): 2.5-4.5 M x 48-128 -3.8...-7.9 %, 8 M -2.5...-4.3 %, 11.7 M -5.4...-5.8 %,
+//    25.6 M -4.6...-5.1 %, 17 M and 47 M level (-1.4...+1.2 %); against the tile-per-block kernel at
+//    40 clients -0.5...-6.6 %;
+//  * from 24 clients on vectors of up to 4 tiles per CU (1.2-4.5 M x 24-40: -0.7...-6.6 % against
+//    the tile-per-block kernel; 8-47 M x 24-32: 0...+4 %, left where they are).
 constexpr uint64_t kParkMinTilesPerCu = 72;
 constexpr int kParkMinClients = 6;
+bool park_wins(int K, uint64_t tiles_per_cu) {
+    if (tiles_per_cu >= kParkMinTilesPerCu) return K >= kParkMinClients;
+    if (tiles_per_cu < 1) return false;
+    return K >= 40 || (K >= 24 && tiles_per_cu <= 4);
+}
 bool takes_park_path(int opt, int K, uint64_t nvec, bool final_form) {
     if (opt != FA_OPT_NONE || !final_form || K > FA_KCHUNK) return false;
     if (g_call_flags & FA_ROUTE_NO_PERSISTENT) return false;
     if (g_shape.stash == -2) return true;
-    if (g_shape.stash <= 0 || K < kParkMinClients) return false;
+    if (g_shape.stash <= 0) return false;
     const uint64_t per_cu = static_cast<uint64_t>(device_cu_count()) * kStashTile;
-    return nvec >= per_cu * kParkMinTilesPerCu;
+    return park_wins(K, nvec / per_cu);
 }
 
 template <int OPT>

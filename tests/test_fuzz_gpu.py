@@ -43,9 +43,11 @@ def test_random_reduce_rounds(seed):
         for it in range(10):
             n, K, opt, code, shift, hp, w = _case(rng)
             # 0: default routing, 1: persistent kernel, 2: tile kernel, 3: wide-batch persistent
-            # kernel where it applies (plain FedAvg), else the persistent kernel
-            forced = int(rng.integers(0, 4))
-            ops.tune(stash={0: 2, 1: -1, 2: 0, 3: -2}[forced])
+            # kernel where it applies (plain FedAvg), else the persistent kernel, 4: the persistent
+            # kernel with the late optimizer epilogue where it applies (final form of an optimizer
+            # round on 16-byte aligned buffers), else the tile kernel
+            forced = int(rng.integers(0, 5))
+            ops.tune(stash={0: 2, 1: -1, 2: 0, 3: -2, 4: -3}[forced])
             with_step = bool(rng.integers(0, 2))
             rounds = int(rng.integers(1, 3))
             base = O.synth_fill(n, 7 + seed, scale=0.05)

@@ -311,8 +311,10 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
     from appfl_amd import ops
     K = 49 if n > 1000000 else 11
     if n > 1000000:
-        assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
-        assert ops.reduce_kernel_name(33, n, "none") == "reduce_kernel"
+        assert ops.reduce_kernel_name(K, n, "none") == "reduce_park_kernel"
+        assert ops.reduce_kernel_name(33, 12_000_000, "none") == "reduce_kernel"
+        assert ops.reduce_kernel_name(K, n, "avgm") == "reduce_late_kernel"
+        assert ops.reduce_kernel_name(K, 3_000_000, "avgm") == "reduce_stash_kernel"
         assert ops.reduce_kernel_name(K, n, "adam") == "reduce_late_kernel"
     code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI,
             "adagrad": O.OPT_ADAGRAD}[opt]
@@ -358,7 +360,7 @@ def test_phased_persistent_kernel_beside_other_work_on_the_chip(opt, hp):
     from appfl_amd import ops
     # tiles per CU beyond what the kernel parks (18 under plain FedAvg, 3 under FedAdam): phased
     n, K = (20_000_004 if opt == "none" else 6_000_004), 49
-    assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
+    assert ops.reduce_kernel_name(K, n, "none") == "reduce_park_kernel"     # the default; forced below
     code = O.OPT_NONE if opt == "none" else O.OPT_ADAM
     base, xs = make_clients(n, K)
     w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
@@ -401,6 +403,10 @@ def test_wide_persistent_kernel_matches_oracle(n, K, nt):
     assert ops.reduce_kernel_name(6, 162_500_000, "none") == "reduce_park_kernel"
     assert ops.reduce_kernel_name(5, 162_500_000, "none") == "reduce_kernel"
     assert ops.reduce_kernel_name(32, 65_000_000, "none") == "reduce_kernel"
+    assert ops.reduce_kernel_name(40, 11_689_512, "none") == "reduce_park_kernel"
+    assert ops.reduce_kernel_name(24, 4_000_000, "none") == "reduce_park_kernel"
+    assert ops.reduce_kernel_name(24, 11_689_512, "none") == "reduce_kernel"
+    assert ops.reduce_kernel_name(100, 200_000, "none") == "reduce_kernel"
     base, xs = make_clients(n, K)
     w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
     g_ref = base.copy()
@@ -781,7 +787,7 @@ def test_meeting_counters_heal_and_later_rounds_keep_their_speed():
     follow (an unhealed counter costs every block a time-out at every meeting)."""
     from appfl_amd import ops
     K, n = 48, 30_000_000                       # 28 tiles per CU: written in phases, with meetings
-    assert ops.reduce_kernel_name(K, n, "none") == "reduce_stash_kernel"
+    assert ops.reduce_kernel_name(K, n, "none") == "reduce_park_kernel"
     d = torch.device("cuda")
     g0 = torch.empty(n, device=d)
     ops.synth_fill(g0, 7, scale=0.05)
@@ -881,7 +887,8 @@ def test_late_epilogue_kernel_where_the_library_routes_to_it():
     assert name(16, 25_557_032, "adam") == name(20, 11_689_512, "adam") == "reduce_kernel"
     assert name(32, 3_000_000, "adam") == name(32, 25_557_032, "avgm") == "reduce_kernel"
     assert name(32, 25_557_032, "none") == "reduce_kernel"
-    assert name(64, 25_557_032, "none") == name(64, 3_000_000, "avgm") == "reduce_stash_kernel"
+    assert name(64, 25_557_032, "none") == "reduce_park_kernel"
+    assert name(64, 3_000_000, "avgm") == "reduce_stash_kernel"
     n, K = 17_000_003, 24
     base, xs = make_clients(n, K, spike=False)
     w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
