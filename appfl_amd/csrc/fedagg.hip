@@ -296,13 +296,69 @@ __device__ __forceinline__ void fold_batch(const ReduceArgs& a, int k, const uns
     }
 }
 
+// The two halves of fold_batch on their own, for callers that keep the next batch's loads in
+// flight while they fold the current one.
+template <int VEC, int VPT, int B, bool NT>
+__device__ __forceinline__ void load_batch(const ReduceArgs& a, int k, const unsigned (&idx)[VPT],
+                                           Pack<VEC> (&xv)[B][VPT]) {
+#pragma unroll
+    for (int u = 0; u < B; ++u)
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) xv[u][p] = load_stream<VEC, NT>(a.x[k + u], idx[p]);
+}
+template <int VEC, int VPT, int B>
+__device__ __forceinline__ void apply_batch(const ReduceArgs& a, int k, const Pack<VEC> (&xv)[B][VPT],
+                                            TileRegs<VEC, VPT>& r) {
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+        const float wk = a.w[k + u];
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float d = xv[u][p].e[j] - r.g[p].e[j];
+                float wd = d * wk;
+                r.s[p].e[j] = r.s[p].e[j] + wd;
+            }
+        }
+    }
+}
+
+// The clients k = 0 .. in whole batches of B, two buffers taking turns: the loads of batch b + 1
+// are issued before batch b is folded, so a wave's loads never drain between batches.  Same
+// additions in the same (client) order as fold_batch after fold_batch.  Returns the clients done.
+template <int VEC, int VPT, int B, bool NT>
+__device__ __forceinline__ int fold_batches_overlapped(const ReduceArgs& a, const unsigned (&idx)[VPT],
+                                                       TileRegs<VEC, VPT>& r) {
+    const int nb = a.K / B;
+    if (nb == 0) return 0;
+    Pack<VEC> xa[B][VPT], xb[B][VPT];
+    load_batch<VEC, VPT, B, NT>(a, 0, idx, xa);
+    int b = 1;                                   // xa holds batch b - 1
+    for (; b + 1 < nb; b += 2) {
+        load_batch<VEC, VPT, B, NT>(a, b * B, idx, xb);
+        apply_batch<VEC, VPT, B>(a, (b - 1) * B, xa, r);
+        load_batch<VEC, VPT, B, NT>(a, (b + 1) * B, idx, xa);
+        apply_batch<VEC, VPT, B>(a, b * B, xb, r);
+    }
+    if (b < nb) {
+        load_batch<VEC, VPT, B, NT>(a, b * B, idx, xb);
+        apply_batch<VEC, VPT, B>(a, (b - 1) * B, xa, r);
+        apply_batch<VEC, VPT, B>(a, b * B, xb, r);
+    } else {
+        apply_batch<VEC, VPT, B>(a, (b - 1) * B, xa, r);
+    }
+    return nb * B;
+}
+
 // Folds the K clients of this launch into the step of the vectors idx[0..VPT) and, on the last
 // client chunk, runs the optimizer epilogue and forms g + step.  Everything stays in registers;
 // the caller decides how the results reach memory.
 // STEP_ONLY: stop after the clients (the averaged step in r.s, g as read in r.g) whatever a.last
 // says -- for callers that run the epilogue themselves, later; g is then read with the caching
 // policy, because the caller reads it again soon.
-template <int OPT, int VEC, int VPT, int U, bool NT, bool STEP_ONLY = false>
+// OVERLAP: batches of U clients with the next batch's loads in flight (U <= 4).
+template <int OPT, int VEC, int VPT, int U, bool NT, bool STEP_ONLY = false, bool OVERLAP = false>
 __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&idx)[VPT],
                                           TileRegs<VEC, VPT>& r) {
     const float* gsrc = a.apply ? a.g : a.g_ro;
@@ -323,7 +379,12 @@ __device__ __forceinline__ void fold_tile(const ReduceArgs& a, const unsigned (&
     // is no multiple of U keeps several clients' loads in flight to the end (with one client at
     // a time, 12 clients at U = 16 ran 20 % slower than 16).
     int k = 0;
-    for (; k + U <= a.K; k += U) fold_batch<VEC, VPT, U, NT>(a, k, idx, r);
+    if constexpr (OVERLAP) {
+        static_assert(U <= 4, "two buffers of U clients x VPT vectors live at once");
+        k = fold_batches_overlapped<VEC, VPT, U, NT>(a, idx, r);
+    } else {
+        for (; k + U <= a.K; k += U) fold_batch<VEC, VPT, U, NT>(a, k, idx, r);
+    }
     if constexpr (U > 8) {
         if (k + 8 <= a.K) { fold_batch<VEC, VPT, 8, NT>(a, k, idx, r); k += 8; }
     }
@@ -432,6 +493,9 @@ __global__ __launch_bounds__(kThreads) void reduce_kernel(const ReduceArgs a) {
 // contiguous, is not.  A vector that the chip can park whole (up to 18 tiles per CU under plain
 // FedAvg) is written in one burst when all its reads are done (+1-2 % over several bursts).
 
+#ifndef FA_FOLD_OVERLAP
+#define FA_FOLD_OVERLAP 0          /* persistent kernels: next batch's loads in flight while one is folded (A/B knob; measured 3-6 % slower in the wide-batch kernel, 2-3 % in the late-epilogue kernel) */
+#endif
 #ifndef FA_PARK_FOLD_AHEAD
 #define FA_PARK_FOLD_AHEAD 2    /* clients ahead per vector in the wide-batch persistent kernel (A/B knob) */
 #endif
@@ -841,7 +905,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
             idx[p] = (off < tlen && i < r1) ? i : r1 - 1;   // idle lanes redo the last vector, never store
         }
         TileRegs<4, VPT> r;
-        fold_tile<OPT, 4, VPT, FA_PARK_FOLD_AHEAD, true>(a, idx, r);
+        fold_tile<OPT, 4, VPT, FA_PARK_FOLD_AHEAD, true, false, FA_FOLD_OVERLAP != 0>(a, idx, r);
         const int j = static_cast<int>((ct + shift) % P);
 #pragma unroll
         for (int p = 0; p < VPT; ++p) {
@@ -962,7 +1026,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceAr
             idx[p] = tile_index(ct, p, live);
         }
         TileRegs<4, VPT> r;
-        fold_tile<FA_OPT_NONE, 4, VPT, FA_LATE_FOLD_AHEAD, true, true>(a, idx, r);
+        fold_tile<FA_OPT_NONE, 4, VPT, FA_LATE_FOLD_AHEAD, true, true, FA_FOLD_OVERLAP != 0>(a, idx, r);
         const int j = static_cast<int>((ct + shift) % P);
 #pragma unroll
         for (int p = 0; p < VPT; ++p) stash[j][p][threadIdx.x] = as_f4(r.s[p]);
