@@ -409,6 +409,9 @@ __global__ __launch_bounds__(kThreads) void reduce_half_kernel(const ReduceHArgs
 #ifndef FA_HALF_LATE_TILES
 #define FA_HALF_LATE_TILES 10
 #endif
+#ifndef FA_HALF_LATE_OVERLAP
+#define FA_HALF_LATE_OVERLAP 1      /* 0: one buffer, a batch's loads are awaited before the next batch is requested (A/B knob; measured 5-13 % slower at 2 clients a batch, 0-4 % slower at 4) */
+#endif
 #ifndef FA_HALF_LATE_AHEAD
 #define FA_HALF_LATE_AHEAD 2
 #endif
@@ -642,6 +645,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const Red
             }
         };
         int b = 0;
+#if FA_HALF_LATE_OVERLAP
 #pragma unroll 1
         for (; b + 2 <= nb; b += 2) {
             request((b + 1) * U, xb, idx);
@@ -650,6 +654,13 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_half_kernel(const Red
             fold((b + 1) * U, xb);
         }
         if (b < nb) fold(b * U, xa);
+#else
+#pragma unroll 1
+        for (; b < nb; ++b) {
+            if (b > 0) request(b * U, xa, idx);
+            fold(b * U, xa);
+        }
+#endif
         for (int k = nb * U; k < a.K; ++k) {
             const float w = a.w[k];
             Raw<VEC> xr[VPT];
