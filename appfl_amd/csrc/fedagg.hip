@@ -963,7 +963,7 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
 #define FA_LATE_DEBUG 0   /* 1-3: timing experiments that drop parts of the epilogue (wrong results) */
 #endif
 constexpr int kLateBatch = FA_LATE_BATCH;   // tiles whose g / m / v the epilogue requests at once
-constexpr unsigned kLatePhaseTiles = 6;
+constexpr unsigned kLatePhaseTiles = 3;
 
 template <int OPT>
 __global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceArgs a) {
@@ -981,9 +981,11 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_late_kernel(const ReduceAr
     if (gridDim.x % 8 == 0) slot = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
     if (a.mt.total) mean_tail(a, gridDim.x - 1u - slot);
     const unsigned most = (total + gridDim.x - 1) / gridDim.x;
-    // phases of six tiles (kernel time against ten, all that LDS holds: -1.5...-2 % at 25 M elements
-    // x 24-32 clients, -1 % on 87-162 M x 32)
-    unsigned P = kLatePhaseTiles;
+    // phases of three tiles (kernel time against six: -1...-2 % at 11.7-25.6 M elements x 24-100
+    // clients, -2...-4.5 % at 47-87 M; against ten, all that LDS holds, another 1-2 % more; two tiles
+    // are better still on long vectors at long client lists but lose 2-3 % at 24 clients); vectors
+    // of up to 8 tiles per CU keep six (4.5 M elements, one burst: -2...-4 % against three; 8 M: -1.6 %)
+    unsigned P = most <= 8u ? 6u : kLatePhaseTiles;
     bool phased = a.sync != 0 && a.sync_word != nullptr;
     if (a.phase_tiles > 0) P = static_cast<unsigned>(a.phase_tiles) < static_cast<unsigned>(S) ? static_cast<unsigned>(a.phase_tiles) : static_cast<unsigned>(S);
     if (most <= P) phased = false;
