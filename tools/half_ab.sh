@@ -1,4 +1,4 @@
-for pass in 1 2; do for l in main s2 s3 s4; do for wl in resnet50_fedadam_k64_bf16 resnet18_fedavg_k100_bf16 resnet50_fedadam_k64_f16; do
+for pass in 1 2; do for l in ${VARIANTS:-main}; do for wl in resnet50_fedadam_k64_bf16 resnet18_fedavg_k100_bf16 resnet50_fedadam_k64_f16; do
   if [ $l = main ]; then unset APPFL_AMD_LIB; else export APPFL_AMD_LIB=appfl_amd/lib/variants/lib_$l.so; fi
   timeout -k 10 100 python bench.py --workload $wl --only --steps 50 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
