@@ -1609,13 +1609,16 @@ int launch_late(const ReduceArgs& a0, hipStream_t st) {
 // 24-32 -2.6...-2.9 %; behind at fewer clients (11.7-17 M x 16 +5...+6 %, x 20 +2 %).  FedAvgM: from
 // 48 clients everywhere (-3.0...-8.4 %) and from 32 on vectors of >= 40 tiles per CU (47 M x 32 / 40
 // -3.6 / -5.4 %, 87 M x 40 -4.7 %); below that its wide tile-per-block shape is ahead (8-25 M x
-// 16-32 +1...+7 %).  fa_tune: stash == -3 forces it at every length and client count, stash <= 0
-// otherwise keeps it off.
+// 16-32 +1...+7 %).  With phases of three tiles the borders moved out a little more: FedAvgM 2.5-3.5 M x
+// 48-100 -4.6...-7.5 % (against the pipelined persistent kernel), 11.7-25.6 M x 40 -1.3...-2 %, 47 M x 24
+// -2.2 %; two-moment optimizers 35 M x 16 -3.2 %, 2.5 M x 32 -1.4 % (x 24 +5 %: stays).  fa_tune: stash ==
+// -3 forces it at every length and client count, stash <= 0 otherwise keeps it off.
 bool late_wins(int opt, int K, uint64_t tiles_per_cu) {
-    if (opt == FA_OPT_AVGM) return (K >= 48 && tiles_per_cu >= 4) || (K >= 32 && tiles_per_cu >= 40);
+    if (opt == FA_OPT_AVGM)
+        return (K >= 48 && tiles_per_cu >= 2) || (K >= 40 && tiles_per_cu >= 4) || (K >= 24 && tiles_per_cu >= 40);
     if (opt < FA_OPT_ADAM) return false;
-    return (K >= 32 && tiles_per_cu >= 4) || (K >= 24 && tiles_per_cu >= 7) || (K >= 20 && tiles_per_cu >= 24) ||
-           (K >= 16 && tiles_per_cu >= 40);
+    return (K >= 32 && tiles_per_cu >= 2) || (K >= 24 && tiles_per_cu >= 7) || (K >= 20 && tiles_per_cu >= 24) ||
+           (K >= 16 && tiles_per_cu >= 32);
 }
 bool stash_wins(int opt, int K, uint64_t tiles_per_cu);
 bool takes_late_path(int opt, int K, uint64_t nvec) {

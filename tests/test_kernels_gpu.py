@@ -314,7 +314,7 @@ def test_persistent_stash_kernel_matches_oracle(opt, hp, n, nt):
         assert ops.reduce_kernel_name(K, n, "none") == "reduce_park_kernel"
         assert ops.reduce_kernel_name(33, 12_000_000, "none") == "reduce_kernel"
         assert ops.reduce_kernel_name(K, n, "avgm") == "reduce_late_kernel"
-        assert ops.reduce_kernel_name(K, 3_000_000, "avgm") == "reduce_stash_kernel"
+        assert ops.reduce_kernel_name(K, 1_500_000, "avgm") == "reduce_kernel"     # under two tiles per CU
         assert ops.reduce_kernel_name(K, n, "adam") == "reduce_late_kernel"
     code = {"none": O.OPT_NONE, "avgm": O.OPT_AVGM, "adam": O.OPT_ADAM, "yogi": O.OPT_YOGI,
             "adagrad": O.OPT_ADAGRAD}[opt]
@@ -885,10 +885,11 @@ def test_late_epilogue_kernel_where_the_library_routes_to_it():
     assert name(64, 25_557_032, "adam") == name(32, 11_689_512, "adam") == "reduce_late_kernel"
     assert name(64, 25_557_032, "avgm") == name(32, 47_000_000, "avgm") == "reduce_late_kernel"
     assert name(16, 25_557_032, "adam") == name(20, 11_689_512, "adam") == "reduce_kernel"
-    assert name(32, 3_000_000, "adam") == name(32, 25_557_032, "avgm") == "reduce_kernel"
+    assert name(32, 1_500_000, "adam") == name(32, 25_557_032, "avgm") == "reduce_kernel"
     assert name(32, 25_557_032, "none") == "reduce_kernel"
     assert name(64, 25_557_032, "none") == "reduce_park_kernel"
-    assert name(64, 3_000_000, "avgm") == "reduce_stash_kernel"
+    assert name(64, 1_500_000, "avgm") == "reduce_kernel"
+    assert name(64, 3_000_000, "avgm") == name(40, 11_689_512, "avgm") == name(16, 35_000_000, "adam") == "reduce_late_kernel"
     n, K = 17_000_003, 24
     base, xs = make_clients(n, K, spike=False)
     w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
