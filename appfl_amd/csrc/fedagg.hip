@@ -871,7 +871,15 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
     const unsigned most = (total + gridDim.x - 1) / gridDim.x;
     unsigned P = static_cast<unsigned>(S);
     bool phased = a.sync != 0 && a.sync_word != nullptr;
-    if (a.phase_tiles > 0 && static_cast<unsigned>(a.phase_tiles) < P) P = static_cast<unsigned>(a.phase_tiles);
+    if (a.phase_tiles > 0) {
+        if (static_cast<unsigned>(a.phase_tiles) < P) P = static_cast<unsigned>(a.phase_tiles);
+    } else if (a.K >= 40 && most > P && most <= 48u) {
+        // long client lists on vectors of 11-48 tiles per CU: phases of three tiles (kernel time against
+        // ten: 11.7 M elements x 64-128 clients -0.5...-1 %, 25.6 M x 48-128 -1.1...-1.4 %, 47 M x 40-100
+        // -1.3...-3 %); ten stay ahead from 82 tiles per CU (87-162 M x 64: +0.4...+1.4 % for three) and
+        // at shorter client lists (162 M x 6-12: +12...+25 %)
+        P = 3u;
+    }
     if (most <= P) phased = false;
     GridMeet meet = {a.sync_word, 0u, false, gridDim.x};
     unsigned shift = 0, meetings = 0;

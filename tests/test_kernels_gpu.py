@@ -432,6 +432,24 @@ def test_wide_persistent_kernel_matches_oracle(n, K, nt):
         ops.tune()
 
 
+def test_wide_persistent_kernel_at_its_default_phases_on_a_long_client_list():
+    """Default routing and phase length at 49 clients on a vector of 12 tiles per CU (the
+    wide-batch persistent kernel in short chip-wide phases, the last one partial): the oracle's
+    bits, two rounds in a row."""
+    from appfl_amd import ops
+    n, K = 12_000_004, 49
+    assert ops.reduce_kernel_name(K, n, "none") == "reduce_park_kernel"
+    base, xs = make_clients(n, K, spike=False)
+    w = [(2 + k) / sum(2 + j for j in range(K)) for k in range(K)]
+    g_ref = base.copy()
+    g = dev(base)
+    dx = [dev(x) for x in xs]
+    for rnd in range(2):
+        O.reduce_opt(xs, w, g_ref, np.zeros_like(base), np.zeros_like(base), O.OPT_NONE)
+        ops.reduce_opt(dx, w, g, None, None, "none")
+        assert_bits(g, g_ref, f"g round {rnd}")
+
+
 def test_wide_persistent_kernel_carries_the_step_of_the_first_client_chunks():
     """K > FA_KCHUNK under FedAdam with the wide-batch kernel forced on: the first chunk's
     launch (plain FedAvg arithmetic, step only) parks and writes the partial step."""
