@@ -838,19 +838,21 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_stash_kernel(const ReduceA
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent kernel with WIDE client batches, for plain FedAvg on very long vectors: one
+// Persistent kernel with plain client batches (the "wide-batch" kernel), for plain FedAvg: one
 // 256-thread block per CU takes every gridDim.x-th tile like reduce_stash_kernel, but folds a tile
-// the way the wide tile-per-block shape does (fold_tile: 16 clients x 4 vectors = 64 loads in
-// flight per lane, no pipelining across tiles), parks the tile's result in LDS and writes ten
-// tiles at a time in the same chip-wide, staggered phases.  Measured against the better of the
-// other two kernels (fraction of peak): 162.5 M elements x 32 clients 0.75 -> 0.85, x 16 0.765 ->
+// with fold_tile (FA_PARK_FOLD_AHEAD = 2 clients x 4 vectors = 8 loads in flight per lane, drained
+// before the next 8; no pipelining across tiles), parks the tile's result in LDS and writes up to
+// ten tiles at a time in the same chip-wide, staggered phases.  Measured with 16 clients in flight,
+// against the better of the other two kernels (fraction of peak; the figures with 2 in flight are
+// with the routing rule, park_wins): 162.5 M elements x 32 clients 0.75 -> 0.85, x 16 0.765 ->
 // 0.80, x 64 0.80 -> 0.83; 120 M x 32 0.75 -> 0.815; 87 M x 16 / 32 / 64 0.77 / 0.75 / 0.79 -> 0.79
 // / 0.81 / 0.82; 325 M x 32 0.79 -> 0.82; level at 65 M elements and at 128 clients, behind below
 // (47 M x 48: 0.76 against 0.79), and far behind under the optimizers, whose epilogue has
 // nothing to hide behind at one wave per SIMD (FedAdam 0.53-0.64 against 0.70-0.75; FedAvgM
 // -1...-3 %).  Short client lists gain as much (8 / 12 clients on 162.5 M: 0.72 / 0.75 -> 0.77 /
-// 0.80).  Phases of ten tiles (all that LDS holds) beat shorter ones here (4 / 6 / 8 / 10
-// tiles on 162.5 M x 32: 0.81 / 0.84 / 0.84 / 0.85).  It takes the final form of a launch
+// 0.80).  Phases of ten tiles (all that LDS holds) beat shorter ones on very long vectors (4 / 6 /
+// 8 / 10 tiles on 162.5 M x 32: 0.81 / 0.84 / 0.84 / 0.85); long client lists on vectors of 11-48
+// tiles per CU take three (see where P is chosen).  It takes the final form of a launch
 // (weighted step and apply, no step output) and, as plain FedAvg whatever the optimizer, the
 // step-only forms (a client chunk that is not the last one; fa_reduce_step).
 template <int OPT>
@@ -952,14 +954,15 @@ __global__ __launch_bounds__(kThreads, 1) void reduce_park_kernel(const ReduceAr
 // The fused kernels above write g, m and v of every tile as soon as its clients are folded: three
 // (two) thin result streams trickling out among the reads, which is what holds the two-moment
 // optimizers at 0.69-0.72 of peak at 16-40 clients, and with three result vectors per tile LDS
-// can only park 3 tiles per phase.  Here a tile's clients are folded the way the wide shape does
-// (16 clients x 4 vectors in flight per lane) into the AVERAGED STEP alone, which is parked in LDS
-// -- one vector per tile, so TEN tiles per phase like plain FedAvg's wide-batch kernel -- and the
-// epilogue runs at the end of the phase over the ten parked tiles: g, m and v are read (g for the
+// can only park 3 tiles per phase.  Here a tile's clients are folded in plain batches
+// (FA_LATE_FOLD_AHEAD = 2 clients x 4 vectors in flight per lane) into the AVERAGED STEP alone, which
+// is parked in LDS -- one vector per tile, so up to TEN tiles per phase like plain FedAvg's
+// wide-batch kernel; three by default, see where P is chosen -- and the
+// epilogue runs at the end of the phase over the parked tiles: g, m and v are read (g for the
 // second time, a few hundred microseconds after the first: 4 of 4 (K + 6) + 4 bytes per
 // parameter), the optimizer formulas evaluated, g, m and v written.  A phase is therefore a long
 // stretch of pure reads followed by a copy-like burst (as many bytes read as written, each CU on
-// its own ten tiles), the two mixes HBM serves best, in the same chip-wide staggered phases.
+// its own tiles), the two mixes HBM serves best, in the same chip-wide staggered phases.
 // Same operations on the same values in the same order as the fused kernels: same bits.
 #ifndef FA_LATE_BATCH
 #define FA_LATE_BATCH 3
